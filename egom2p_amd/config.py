@@ -1,0 +1,84 @@
+"""Model / modality configuration for the EgoM2P hot path.
+
+Mirrors the information the reference keeps in `egom2p/data/modality_info.py:59-141`
+(vocab size, max tokens, type, sha256-derived id) and the registry entries of
+`egom2p/models/egom2p_model.py:882-1196` (depth / width / heads per name).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+
+def uint15_hash(name: str) -> int:
+    """Modality id = sha256(name) mod 2^15 (reference: `egom2p/utils/misc.py:39-41`)."""
+    return int(hashlib.sha256(name.encode("utf-8")).hexdigest(), 16) % (2 ** 15)
+
+
+@dataclass(frozen=True)
+class Modality:
+    name: str
+    vocab_size: int
+    max_tokens: int          # number of clip positions of this modality
+    kind: str                # 'video' (3-D sin-cos, 5x32x32) or 'seq1d' (1-D sin-cos, 30)
+    type: str                # reference 'type' field: img / cam / gaze
+    grid: Tuple[int, int, int] = (0, 0, 0)   # (t, h, w) for video
+
+    @property
+    def id(self) -> int:
+        return uint15_hash(self.name)
+
+
+# The four modalities of the mod4 configs (reference `modality_info.py:59-69,75-85,116-141`).
+TOK_RGB = Modality("tok_rgb", 64000, 5120, "video", "img", (5, 32, 32))
+TOK_DEPTH = Modality("tok_depth", 64000, 5120, "video", "img", (5, 32, 32))
+TOK_CAM = Modality("tok_cam", 256, 30, "seq1d", "cam")
+TOK_GAZE = Modality("tok_gaze", 256, 30, "seq1d", "gaze")
+
+MODALITIES: Dict[str, Modality] = {m.name: m for m in (TOK_RGB, TOK_DEPTH, TOK_CAM, TOK_GAZE)}
+
+
+@dataclass(frozen=True)
+class ModelCfg:
+    """Shape of one EgoM2P variant (SwiGLU, bias-free, LayerNorm(no bias, eps 1e-6))."""
+    name: str
+    dim: int
+    encoder_depth: int
+    decoder_depth: int
+    num_heads: int
+    mlp_ratio: float = 4.0
+    modalities: Tuple[str, ...] = ("tok_rgb", "tok_depth", "tok_cam", "tok_gaze")
+    share_embedding: bool = True       # decoder to_logits tied to decoder token_emb
+    eps: float = 1e-6
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.num_heads
+
+    @property
+    def mlp_hidden(self) -> int:
+        # GatedMlp: int(2 * int(dim * mlp_ratio) / 3)  (reference `egom2p_utils.py:161,349`)
+        return int(2 * int(self.dim * self.mlp_ratio) / 3)
+
+    @property
+    def mods(self) -> List[Modality]:
+        return [MODALITIES[m] for m in self.modalities]
+
+    @property
+    def total_positions(self) -> int:
+        return sum(m.max_tokens for m in self.mods)
+
+
+# Registered SwiGLU/no-bias variants (reference `egom2p_model.py:982-1120`) plus the two
+# build-owned configs named by BASELINE.json (ego-tiny plumbing config, ego-L MFMA-aligned).
+MODEL_CFGS: Dict[str, ModelCfg] = {
+    "egom2p_tiny_6e_6d_swiglu_nobias": ModelCfg("egom2p_tiny_6e_6d_swiglu_nobias", 384, 6, 6, 6),
+    "egom2p_small_8e_8d_swiglu_nobias": ModelCfg("egom2p_small_8e_8d_swiglu_nobias", 512, 8, 8, 8),
+    "egom2p_base_12e_12d_swiglu_nobias": ModelCfg("egom2p_base_12e_12d_swiglu_nobias", 768, 12, 12, 12),
+    "egom2p_large_24e_24d_swiglu_nobias": ModelCfg("egom2p_large_24e_24d_swiglu_nobias", 1020, 24, 24, 15),
+    # build-owned
+    "ego_tiny_2e_2d": ModelCfg("ego_tiny_2e_2d", 128, 2, 2, 2, modalities=("tok_cam", "tok_gaze")),
+    "ego_b_2e_2d": ModelCfg("ego_b_2e_2d", 768, 2, 2, 12),
+    "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
+}

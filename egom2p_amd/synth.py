@@ -1,0 +1,216 @@
+"""Build-owned counter-based generator for weights and synthetic clips.
+
+value = f(tensor-name, flat index, seed) using only integer arithmetic plus one exact
+int->float scaling, so this container (where the reference model is run to make goldens)
+and the GPU box regenerate bit-identical tensors without shipping 1.6 GB of weights.
+(SURVEY.md section 8c "build-owned counter-based generator".)
+
+Nothing here is taken from the reference; the *distributions* follow its init scheme
+(`egom2p/models/egom2p_model.py:185-222`): xavier-uniform linears with qkv / kv treated as
+3 / 2 separate matrices, N(0, 0.02) embeddings, LayerNorm weight 1 (we perturb LN weights and
+the one Linear bias slightly so their gradients are exercised by parity tests).
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .config import ModelCfg, Modality, MODALITIES
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _key(name: str, seed: int) -> np.uint64:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return np.uint64(int.from_bytes(h[:8], "little"))
+
+
+def _hash_u64(name: str, n: int, seed: int, start: int = 0) -> np.ndarray:
+    """splitmix64 finaliser over counter = key + (start+i) * golden."""
+    with np.errstate(over="ignore"):
+        x = (np.arange(start, start + n, dtype=np.uint64) * _GOLD) + _key(name, seed)
+        x = (x ^ (x >> np.uint64(30))) * _M1
+        x = (x ^ (x >> np.uint64(27))) * _M2
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _chunks(n: int, step: int = 1 << 24):
+    for s in range(0, n, step):
+        yield s, min(step, n - s)
+
+
+def uniform(name: str, shape: Sequence[int], lo: float, hi: float, seed: int = 0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    for s, c in _chunks(n):
+        u = (_hash_u64(name, c, seed, s) >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
+        out[s:s + c] = (lo + (hi - lo) * u).astype(np.float32)
+    return torch.from_numpy(out.reshape(tuple(shape)))
+
+
+_IH_STD = math.sqrt(4.0 * ((65536.0 ** 2 - 1.0) / 12.0))  # std of the sum of four uniform u16
+
+
+def normal(name: str, shape: Sequence[int], std: float, seed: int = 0, mean: float = 0.0) -> torch.Tensor:
+    """Irwin-Hall(4) approximation of a Gaussian from the four 16-bit limbs of one hash."""
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    for s, c in _chunks(n):
+        x = _hash_u64(name, c, seed, s)
+        m = np.uint64(0xFFFF)
+        t = ((x & m) + ((x >> np.uint64(16)) & m) + ((x >> np.uint64(32)) & m) + (x >> np.uint64(48))).astype(np.float64)
+        out[s:s + c] = (mean + (t - 2.0 * 65535.0) * (std / _IH_STD)).astype(np.float32)
+    return torch.from_numpy(out.reshape(tuple(shape)))
+
+
+def randint(name: str, shape: Sequence[int], high: int, seed: int = 0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    x = (_hash_u64(name, n, seed) >> np.uint64(11)) % np.uint64(high)
+    return torch.from_numpy(x.astype(np.int64).reshape(tuple(shape)))
+
+
+def permutation(name: str, n: int, seed: int = 0) -> np.ndarray:
+    return np.argsort(_hash_u64(name, n, seed), kind="stable")
+
+
+# ----------------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------------
+
+def _xavier(name, out_f, in_f, seed, fan_out=None):
+    fan_out = out_f if fan_out is None else fan_out
+    a = math.sqrt(6.0 / float(fan_out + in_f))
+    return uniform(name, (out_f, in_f), -a, a, seed)
+
+
+def _ln(name, dim, seed, sd):
+    sd[name + ".weight"] = normal(name + ".weight", (dim,), 0.1, seed, mean=1.0)
+    sd[name + ".bias"] = torch.zeros(dim)  # zero *buffer* in the reference (LayerNorm(bias=False))
+
+
+def build_state_dict(cfg: ModelCfg, seed: int = 0, posemb: bool = True) -> Dict[str, torch.Tensor]:
+    """State dict with the reference's key layout."""
+    from .posemb import build_pos_emb
+
+    D, F = cfg.dim, cfg.mlp_hidden
+    sd: Dict[str, torch.Tensor] = {}
+    for m in cfg.mods:
+        e = f"encoder_embeddings.{m.name}"
+        d = f"decoder_embeddings.{m.name}"
+        sd[f"{e}.mod_emb"] = normal(f"{e}.mod_emb", (1, 1, D), 0.02, seed)
+        sd[f"{e}.token_emb.weight"] = normal(f"{e}.token_emb.weight", (m.vocab_size, D), 0.02, seed)
+        sd[f"{d}.mod_emb"] = sd[f"{e}.mod_emb"]            # shared Parameter (egom2p_model.py:179-183)
+        sd[f"{d}.token_emb.weight"] = normal(f"{d}.token_emb.weight", (m.vocab_size, D), 0.02, seed)
+        if cfg.share_embedding:
+            sd[f"{d}.to_logits.weight"] = sd[f"{d}.token_emb.weight"]  # tied (decoder_embeddings.py:447-449)
+        else:
+            sd[f"{d}.to_logits.weight"] = _xavier(f"{d}.to_logits.weight", m.vocab_size, D, seed)
+        if posemb:
+            pe = build_pos_emb(m, D)
+            sd[f"{e}.pos_emb"] = pe
+            sd[f"{d}.pos_emb"] = pe
+    for i in range(cfg.encoder_depth):
+        p = f"encoder.{i}"
+        _ln(f"{p}.norm1", D, seed, sd)
+        _ln(f"{p}.norm2", D, seed, sd)
+        sd[f"{p}.attn.qkv.weight"] = _xavier(f"{p}.attn.qkv.weight", 3 * D, D, seed, fan_out=D)
+        sd[f"{p}.attn.proj.weight"] = _xavier(f"{p}.attn.proj.weight", D, D, seed)
+        sd[f"{p}.mlp.fc1.weight"] = _xavier(f"{p}.mlp.fc1.weight", F, D, seed)
+        sd[f"{p}.mlp.fc2.weight"] = _xavier(f"{p}.mlp.fc2.weight", D, F, seed)
+        sd[f"{p}.mlp.fc3.weight"] = _xavier(f"{p}.mlp.fc3.weight", F, D, seed)
+    _ln("encoder_norm", D, seed, sd)
+    sd["decoder_proj_context.weight"] = _xavier("decoder_proj_context.weight", D, D, seed)
+    sd["decoder_proj_context.bias"] = normal("decoder_proj_context.bias", (D,), 0.02, seed)
+    for i in range(cfg.decoder_depth):
+        p = f"decoder.{i}"
+        for n in ("norm1", "query_norm", "context_norm", "norm2"):
+            _ln(f"{p}.{n}", D, seed, sd)
+        sd[f"{p}.self_attn.qkv.weight"] = _xavier(f"{p}.self_attn.qkv.weight", 3 * D, D, seed, fan_out=D)
+        sd[f"{p}.self_attn.proj.weight"] = _xavier(f"{p}.self_attn.proj.weight", D, D, seed)
+        sd[f"{p}.cross_attn.q.weight"] = _xavier(f"{p}.cross_attn.q.weight", D, D, seed)
+        sd[f"{p}.cross_attn.kv.weight"] = _xavier(f"{p}.cross_attn.kv.weight", 2 * D, D, seed, fan_out=D)
+        sd[f"{p}.cross_attn.proj.weight"] = _xavier(f"{p}.cross_attn.proj.weight", D, D, seed)
+        sd[f"{p}.mlp.fc1.weight"] = _xavier(f"{p}.mlp.fc1.weight", F, D, seed)
+        sd[f"{p}.mlp.fc2.weight"] = _xavier(f"{p}.mlp.fc2.weight", D, F, seed)
+        sd[f"{p}.mlp.fc3.weight"] = _xavier(f"{p}.mlp.fc3.weight", F, D, seed)
+    _ln("decoder_norm", D, seed, sd)
+    sd["mask_token"] = normal("mask_token", (1, 1, D), 0.02, seed)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------
+# synthetic clips (the `mod_dict` input contract)
+# ----------------------------------------------------------------------------------------
+
+CANONICAL_BUDGETS = {  # (k_in, k_tgt) per modality: N = M = 2048 exactly
+    "tok_rgb": (1009, 1009), "tok_depth": (1009, 1009), "tok_cam": (15, 15), "tok_gaze": (15, 15),
+}
+
+
+def make_clip_batch(cfg: ModelCfg, batch: int, budgets: Optional[Dict[str, Sequence[Tuple[int, int]]]] = None,
+                    seed: int = 0, sample_offset: int = 0) -> Dict[str, Dict[str, torch.Tensor]]:
+    """Synthetic `mod_dict` for `batch` clips.
+
+    Per modality and sample: a hash-derived permutation of its positions; the first k_in are
+    encoder inputs, the next k_tgt decoder targets (disjoint, like `masking.py:248-260`);
+    masks are True = ignore; `decoder_attention_mask` carries k_tgt at the first target
+    position (`masking.py:262-264`).  `budgets[mod]` is one (k_in, k_tgt) pair, or a list of
+    pairs, one per sample (ragged case).
+    """
+    out: Dict[str, Dict[str, torch.Tensor]] = {}
+    for m in cfg.mods:
+        n = m.max_tokens
+        bud = (budgets or CANONICAL_BUDGETS)[m.name]
+        if isinstance(bud[0], int):
+            bud = [tuple(bud)] * batch
+        shape = (batch,) + (m.grid if m.kind == "video" else (n,))
+        ids = torch.empty((batch, n), dtype=torch.int64)
+        in_mask = torch.ones((batch, n), dtype=torch.bool)
+        tg_mask = torch.ones((batch, n), dtype=torch.bool)
+        dam = torch.zeros((batch, n), dtype=torch.int32)
+        for b in range(batch):
+            s = sample_offset + b
+            ids[b] = randint(f"clip{s}.{m.name}.ids", (n,), m.vocab_size, seed)
+            perm = permutation(f"clip{s}.{m.name}.perm", n, seed)
+            k_in, k_tg = bud[b]
+            assert k_in + k_tg <= n
+            in_mask[b, torch.from_numpy(perm[:k_in].copy())] = False
+            tg_mask[b, torch.from_numpy(perm[k_in:k_in + k_tg].copy())] = False
+            # first target position (argmin of mask + arange*1e-6 == first False, else 0)
+            first = int(np.min(perm[k_in:k_in + k_tg])) if k_tg > 0 else 0
+            dam[b, first] = k_tg
+        out[m.name] = {
+            "tensor": ids.reshape(shape),
+            "input_mask": in_mask,
+            "target_mask": tg_mask,
+            "decoder_attention_mask": dam,
+        }
+    return out
+
+
+def dirichlet_budgets(cfg: ModelCfg, batch: int, n_in: int, n_tgt: int, seed: int = 0,
+                      alphas: Sequence[float] = (0.01, 0.1, 1.0, 10.0)) -> Dict[str, List[Tuple[int, int]]]:
+    """Ragged budgets in the spirit of the reference's Dirichlet mixture
+    (`cfgs/default/egom2p/alphas_mixture/main/mix_mod4_all2all_uni.yaml`, `masking.py:181-234`):
+    per sample draw input/target shares from Dirichlet(alpha) (alpha picked from `alphas`),
+    clamp to what each modality has left.  Deterministic (numpy Generator seeded per sample)."""
+    mods = cfg.mods
+    res: Dict[str, List[Tuple[int, int]]] = {m.name: [] for m in mods}
+    for b in range(batch):
+        rng = np.random.default_rng([seed, b, 0xE60])
+        a_in = alphas[int(rng.integers(len(alphas)))]
+        a_tg = alphas[int(rng.integers(len(alphas)))]
+        p_in = rng.dirichlet([a_in] * len(mods))
+        p_tg = rng.dirichlet([a_tg] * len(mods))
+        for j, m in enumerate(mods):
+            k_in = min(int(round(p_in[j] * n_in)), m.max_tokens)
+            k_tg = min(int(round(p_tg[j] * n_tgt)), m.max_tokens - k_in)
+            res[m.name].append((k_in, k_tg))
+    return res
