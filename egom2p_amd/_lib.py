@@ -1,0 +1,99 @@
+"""ctypes binding of libegom2p_hip.so (the C-ABI declared in include/egom2p_hip.h).
+
+The product path fails loudly when the HIP library is missing: there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libegom2p_hip.so")
+MAX_MODS = 8
+
+EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class CompactDesc(C.Structure):
+    _fields_ = [
+        ("n_mods", i32), ("n_keep", i32), ("is_decoder", i32),
+        ("mask", vp * MAX_MODS), ("ids", vp * MAX_MODS), ("dam", vp * MAX_MODS),
+        ("n_pos", i32 * MAX_MODS), ("mod_id", i32 * MAX_MODS),
+        ("ids_keep", vp), ("pad", vp), ("mod_mask", vp), ("slot", vp), ("local", vp), ("tok", vp),
+        ("ks", vp), ("ke", vp), ("n_valid", vp), ("seg", vp), ("err", vp),
+    ]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [
+        ("table", vp * MAX_MODS), ("pos", vp * MAX_MODS), ("mod", vp * MAX_MODS), ("base_vec", vp),
+        ("slot", vp), ("local", vp), ("tok", vp), ("x", vp), ("emb", vp), ("rows", i64), ("D", i32),
+    ]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [
+        ("dtable", vp * MAX_MODS), ("dmod", vp * MAX_MODS), ("dbase", vp), ("dx", vp), ("d2", vp),
+        ("slot", vp), ("tok", vp), ("rows", i64), ("D", i32), ("n_mods", i32),
+    ]
+
+
+_SIGS = {
+    "ego_abi_version": [],
+    "ego_compact": [C.POINTER(CompactDesc), i32, vp],
+    "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
+    "ego_embed_bwd": [C.POINTER(EmbedBwdDesc), vp],
+    "ego_loss_perm": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
+    "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
+    "ego_attn_fwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64,
+                         i32, i32, i32, i32, f32, vp],
+    "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
+                         vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
+    "ego_swiglu_fwd": [vp, vp, i64, i32, vp],
+    "ego_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
+    "ego_ce_fwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp],
+    "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp],
+    "ego_loss_finalize": [vp, vp, i32, vp, vp],
+    "ego_cast_weight": [vp, i32, i32, i64, vp, i64, vp, i64, i32, vp],
+    "ego_cast_f32_bf16": [vp, vp, i64, vp],
+    "ego_bias_grad": [vp, i64, i32, vp, vp],
+    "ego_grad_sqnorm": [vp, i64, vp, vp],
+    "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
+    "ego_grad_scale": [vp, i64, f32, f32, vp, vp],
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class EgoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EgoHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C egom2p_amd/csrc`). There is no CPU fallback for the product path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = i32
+        if lib.ego_abi_version() != 1:
+            raise EgoHipError("libegom2p_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise EgoHipError(f"{what} failed: {'bad arguments' if rc == 1 else 'kernel launch failed'} (rc={rc})")

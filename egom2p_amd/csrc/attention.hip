@@ -1,0 +1,535 @@
+// Fused attention for head_dim 64 on gfx950 (flash-style, nothing N x N ever reaches HBM).
+//
+// Replaces Attention.forward / CrossAttention.forward of the reference
+// (egom2p/models/egom2p_utils.py:185-205, 222-244): (q k^T) * d^-0.5 -> masked_fill -> softmax -> @ v,
+// and their autograd backward.  The reference's boolean masks (encoder key padding,
+// egom2p_model.py:389-394; decoder block-diagonal-by-modality mask, :446-481) are passed as one
+// allowed key interval [ks, ke) per query row (never materialised).  A row whose interval is empty
+// reproduces the reference's masked_fill(-finfo.max)+softmax result: uniform attention over all keys
+// (implemented as score scale 0 over [0, Nk)).
+//
+// Layout choices (32x32x16 bf16 MFMA, wave = 64):
+//   * forward / dQ: one wave owns 32 query rows; S^T = K.Q^T is computed with the key index in the
+//     accumulator rows and the query on the lane, so the softmax statistics are per-lane scalars and
+//     the S^T accumulator registers are directly the B operand of O^T = V^T.P^T (no LDS round trip).
+//   * dK/dV: one wave owns 32 keys (key on the lane); P and dS accumulators are directly the
+//     B operands of dV^T = dO^T.P and dK^T = Q^T.dS.  dQ is produced by its own query-major kernel,
+//     so there are no atomics and the result is bitwise reproducible.
+//   * K/V (or Q/dO) tiles of 64 rows x 64 dims are staged through LDS in one XOR-swizzled image that is
+//     bank-conflict free for both the ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads.
+#include "common.h"
+#include "egom2p_hip.h"
+#include <limits.h>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int TILE_BYTES = 64 * 128;  // 64 rows x 64 bf16
+
+struct AttnArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;
+    bf16_t* O; long o_bs, o_rs;
+    float* LSE;                 // [B,H,Nq] log2-domain log-sum-exp of the scaled scores
+    const int* ks; const int* ke;  // interval of query row (b,q) at [b*r_bs + q*r_rs]
+    long r_bs, r_rs;
+    int B, H, Nq, Nk;
+    float scale;
+    // backward only
+    const bf16_t* dO; long do_bs, do_rs;
+    const float* DELTA;         // [B,H,Nq]
+    bf16_t* dQ; long dq_bs, dq_rs;
+    bf16_t* dK; long dk_bs, dk_rs;
+    bf16_t* dV; long dv_bs, dv_rs;
+};
+
+// byte offset of 16-byte chunk c16 (0..7) of row r in the swizzled [64][64] bf16 image
+__device__ __forceinline__ int att_off(int r, int c16) {
+    const int v = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+    return r * 128 + ((c16 ^ v) << 4);
+}
+
+// MFMA 32x32x16 operand whose 32 rows are tile rows rb*32..+31 and whose k index is the tile column
+// (k-step s covers columns 16s..16s+15): lane (row l&31, half l>>5) reads 8 consecutive columns.
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int s, int lane) {
+    return *(const bf16x8*)(tile + att_off(rb * 32 + (lane & 31), 2 * s + (lane >> 5)));
+}
+
+// MFMA 32x32x16 operand whose 32 rows are tile COLUMNS db*32..+31 and whose k index is the tile row,
+// in the permuted order an accumulator tile presents its rows (k-step sp covers tile rows 16sp..16sp+15;
+// element j of lane half h is row 16sp + 8(j>>2) + 4h + (j&3)).
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int db, int sp, int lane) {
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3, h = g >> 1;
+    const int c16 = 4 * db + 2 * (g & 1) + (p >> 1), sub = (p & 1) * 8;
+    const int r0 = 16 * sp + 4 * h + q, r1 = r0 + 8;
+    s16x4 lo = lds_read_tr16(tile + att_off(r0, c16) + sub);
+    s16x4 hi = lds_read_tr16(tile + att_off(r1, c16) + sub);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int x) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * x + j];
+    return r;
+}
+
+// accumulator row index (0..31) of register r for lane half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// store a transposed 64(d) x 32(rows on lanes) accumulator pair as bf16 rows [row][64 d]
+__device__ __forceinline__ void store_rows_bf16(bf16_t* dst, const f32x16 (&t)[2], float mul, int hh) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + 8 * g + 4 * hh;
+            u32x2 o = {pack_bf16x2(t[db][4 * g] * mul, t[db][4 * g + 1] * mul),
+                       pack_bf16x2(t[db][4 * g + 2] * mul, t[db][4 * g + 3] * mul)};
+            *(u32x2*)(dst + d0) = o;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qrow = min(q0 + ql, p.Nq - 1);
+
+    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
+    float sc = p.scale * LOG2E;
+    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
+    const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
+    const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
+    int* rng = (int*)(smem + 4 * TILE_BYTES);
+    if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
+    __syncthreads();
+    const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
+    const int kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
+
+    const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+
+    const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
+    const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
+    u32x4 rk[2], rv[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            const int key = kt * 64 + r;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rk[i] = (key < p.Nk) ? *(const u32x4*)(Kb + (long)key * p.k_rs + c * 8) : z;
+            rv[i] = (key < p.Nk) ? *(const u32x4*)(Vb + (long)key * p.v_rs + c * 8) : z;
+        }
+    };
+    auto store_tile = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rk[i];
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rv[i];
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+    float m = NEG_BIG, l = 0.f;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int s_ = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);
+        const char* Kt = smem + s_ * 2 * TILE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
+        }
+        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = st[kb][r] * sc;
+                if (!full) {
+                    const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
+                    v = (kidx >= ks && kidx < ke) ? v : NEG_BIG;
+                }
+                st[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(st[kb][r] - mnew);
+                if (!full) pv = (st[kb][r] <= NEG_BIG) ? 0.f : pv;
+                rs += pv;
+                st[kb][r] = pv;
+            }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const bf16x8 pf = pack8(st[sp >> 1], sp & 1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, db, sp, lane), pf, ot[db], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) store_tile(s_ ^ 1);
+        __syncthreads();
+    }
+
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    if (q0 + ql < p.Nq) {
+        store_rows_bf16(p.O + (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64, ot, inv, hh);
+        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = m + __builtin_amdgcn_logf(lt);  // v_log_f32 = log2
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// ---------------------------------------------------------------------------------------------
+__global__ void attn_delta_kernel(const bf16_t* O, long o_bs, long o_rs, const bf16_t* dO, long do_bs, long do_rs,
+                                  float* DELTA, int B, int H, int Nq) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * Nq) return;
+    const int b = wave / Nq, q = wave % Nq;
+    const bf16_t* o = O + (long)b * o_bs + (long)q * o_rs;
+    const bf16_t* g = dO + (long)b * do_bs + (long)q * do_rs;
+    for (int c = lane; c < H * 16; c += 64) {      // 4-element chunks; 16 chunks per head
+        const u32x2 a = *(const u32x2*)(o + c * 4), d = *(const u32x2*)(g + c * 4);
+        float s = bf16_to_f32(a[0] & 0xffff) * bf16_to_f32(d[0] & 0xffff) + bf16_to_f32(a[0] >> 16) * bf16_to_f32(d[0] >> 16) +
+                  bf16_to_f32(a[1] & 0xffff) * bf16_to_f32(d[1] & 0xffff) + bf16_to_f32(a[1] >> 16) * bf16_to_f32(d[1] >> 16);
+#pragma unroll
+        for (int o_ = 8; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 64);
+        if ((lane & 15) == 0) DELTA[((long)b * H + (c >> 4)) * Nq + q] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, query-major: dQ
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qrow = min(q0 + ql, p.Nq - 1);
+
+    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
+    float sc = p.scale * LOG2E, gsc = p.scale;
+    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
+    const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
+    int* rng = (int*)(smem + 4 * TILE_BYTES);
+    if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
+    __syncthreads();
+    const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
+    const int kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
+
+    const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
+    const bf16_t* Gp = p.dO + (long)b * p.do_bs + (long)qrow * p.do_rs + h * 64;
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+        gf[s] = *(const bf16x8*)(Gp + 16 * s + 8 * hh);
+    }
+    const float lse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];
+    const float delta = p.DELTA[((long)b * p.H + h) * p.Nq + qrow];
+
+    const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
+    const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
+    u32x4 rk[2], rv[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            const int key = kt * 64 + r;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rk[i] = (key < p.Nk) ? *(const u32x4*)(Kb + (long)key * p.k_rs + c * 8) : z;
+            rv[i] = (key < p.Nk) ? *(const u32x4*)(Vb + (long)key * p.v_rs + c * 8) : z;
+        }
+    };
+    auto store_tile = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rk[i];
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rv[i];
+        }
+    };
+
+    f32x16 dqt[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int s_ = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);
+        const char* Kt = smem + s_ * 2 * TILE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+        f32x16 st[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[kb][i] = 0.f; dp[kb][i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp[kb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
+                const bool ok = (kidx >= ks && kidx < ke);
+                const float pv = ok ? __builtin_amdgcn_exp2f(st[kb][r] * sc - lse2) : 0.f;
+                st[kb][r] = pv * (dp[kb][r] - delta) * gsc;
+            }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const bf16x8 dsf = pack8(st[sp >> 1], sp & 1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, db, sp, lane), dsf, dqt[db], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) store_tile(s_ ^ 1);
+        __syncthreads();
+    }
+    if (q0 + ql < p.Nq)
+        store_rows_bf16(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * 64, dqt, 1.f, hh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, key-major: dK, dV
+// ---------------------------------------------------------------------------------------------
+constexpr int AUX_OFF = 4 * TILE_BYTES;           // per stage: lse2[64] delta[64] ks[64] ke[64] = 1 KiB
+constexpr int DKV_LDS = 4 * TILE_BYTES + 2 * 1024;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const int kl = lane & 31, hh = lane >> 5;
+    const int kidx = kw0 + kl;
+    const int krow = min(kidx, p.Nk - 1);
+
+    const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)krow * p.k_rs + h * 64;
+    const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)krow * p.v_rs + h * 64;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *(const bf16x8*)(Kp + 16 * s + 8 * hh);
+        vf[s] = *(const bf16x8*)(Vp + 16 * s + 8 * hh);
+    }
+
+    const bf16_t* Qb = p.Q + (long)b * p.q_bs + h * 64;
+    const bf16_t* Gb = p.dO + (long)b * p.do_bs + h * 64;
+    const float* LSEb = p.LSE + ((long)b * p.H + h) * p.Nq;
+    const float* DELb = p.DELTA + ((long)b * p.H + h) * p.Nq;
+    const int* KSb = p.ks + b * p.r_bs;
+    const int* KEb = p.ke + b * p.r_bs;
+
+    u32x4 rq[2], rg[2];
+    float a_lse = 0.f, a_del = 0.f;
+    int a_ks = INT_MAX, a_ke = 0;
+    auto load_tile = [&](int qt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            const int row = qt * 64 + r;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rq[i] = (row < p.Nq) ? *(const u32x4*)(Qb + (long)row * p.q_rs + c * 8) : z;
+            rg[i] = (row < p.Nq) ? *(const u32x4*)(Gb + (long)row * p.do_rs + c * 8) : z;
+        }
+        if (tid < 64) {
+            const int row = qt * 64 + tid;
+            if (row < p.Nq) {
+                a_lse = LSEb[row]; a_del = DELb[row];
+                a_ks = KSb[row * p.r_rs]; a_ke = min(KEb[row * p.r_rs], p.Nk);
+                if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
+            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }
+        }
+    };
+    auto store_tile = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rq[i];
+            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rg[i];
+        }
+        if (tid < 64) {
+            float* af = (float*)(smem + AUX_OFF + s * 1024);
+            int* ai = (int*)(smem + AUX_OFF + s * 1024 + 512);
+            af[tid] = a_lse; af[64 + tid] = a_del; ai[tid] = a_ks; ai[64 + tid] = a_ke;
+        }
+    };
+
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
+    const float c_sc = p.scale * LOG2E;
+
+    const int nqt = (p.Nq + 63) >> 6;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int s_ = qt & 1;
+        if (qt + 1 < nqt) load_tile(qt + 1);
+        const char* Qt = smem + s_ * 2 * TILE_BYTES;
+        const char* Gt = Qt + TILE_BYTES;
+        const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);
+        const int* ai = (const int*)(smem + AUX_OFF + s_ * 1024 + 512);
+
+        // does any row of this q tile look at this wave's 32 keys?
+        int t_ks = ai[lane], t_ke = ai[64 + lane];
+        t_ks = (t_ks < 0) ? 0 : t_ks;
+        const int lo = wave_min_i(t_ks), hi = wave_max_i(t_ke);
+        if (hi > kw0 && lo < kw0 + 32) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 st, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, qb, s, lane), kf[s], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gt, qb, s, lane), vf[s], dp, 0, 0, 0);
+                }
+                f32x16 pv, ds;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int qb0 = qb * 32 + 8 * g + 4 * hh;           // 4 consecutive q rows
+                    const f32x4 lse4 = *(const f32x4*)(af + qb0);
+                    const f32x4 del4 = *(const f32x4*)(af + 64 + qb0);
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    const i32x4 ks4 = *(const i32x4*)(ai + qb0);
+                    const i32x4 ke4 = *(const i32x4*)(ai + 64 + qb0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const bool ok = (kidx >= ks4[e]) && (kidx < ke4[e]);
+                        const bool flat = ks4[e] < 0;
+                        const float x = flat ? 0.f : st[r] * c_sc;
+                        const float pe = ok ? __builtin_amdgcn_exp2f(x - lse4[e]) : 0.f;
+                        pv[r] = pe;
+                        ds[r] = flat ? 0.f : pe * (dp[r] - del4[e]) * p.scale;
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int sp = 2 * qb + x;
+                    const bf16x8 pf = pack8(pv, x), dsf = pack8(ds, x);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Gt, db, sp, lane), pf, dvt[db], 0, 0, 0);
+                        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, db, sp, lane), dsf, dkt[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (qt + 1 < nqt) store_tile(s_ ^ 1);
+        __syncthreads();
+    }
+    if (kidx < p.Nk) {
+        store_rows_bf16(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * 64, dkt, 1.f, hh);
+        store_rows_bf16(p.dV + (long)b * p.dv_bs + (long)krow * p.dv_rs + h * 64, dvt, 1.f, hh);
+    }
+}
+
+bool check(const AttnArgs& a) {
+    return a.B > 0 && a.H > 0 && a.Nq > 0 && a.Nk > 0 && a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 &&
+           a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0;
+}
+
+}  // namespace
+
+extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
+                                const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, float* LSE,
+                                const int* ks, const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk,
+                                float scale, hipStream_t stream) {
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
+                                const void* V, long v_bs, long v_rs, const void* O, long o_bs, long o_rs,
+                                const void* dO, long do_bs, long do_rs, const float* LSE, float* DELTA,
+                                void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
+                                void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs,
+                                int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA;
+    a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
+    a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
+    a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
+    {
+        const long waves = (long)B * Nq;
+        const int blocks = (int)((waves * 64 + 255) / 256);
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)O, o_bs, o_rs,
+                           (const bf16_t*)dO, do_bs, do_rs, DELTA, B, H, Nq);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}

@@ -1,0 +1,70 @@
+// Shared device helpers for the EgoM2P gfx950 kernels.  CDNA4 only: wave = 64 lanes,
+// MFMA bf16 tiles, 160 KiB LDS per CU.  No portability layers on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits in memory
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));       // one MFMA A/B fragment (4 VGPRs)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));         // 16x16 accumulator
+typedef float f32x16 __attribute__((ext_vector_type(16)));       // 32x32 accumulator
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define EGO_OK 0
+#define EGO_ERR_ARG 1
+#define EGO_ERR_LAUNCH 2
+
+#define LAUNCH_CHECK()                                        \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return EGO_ERR_LAUNCH;         \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// LDS transposed read: per 16-lane group a 4(row) x 16(col) block of 16-bit elements; lane i of
+// the group receives column i of the 4 rows.  Lane 4q+p supplies the address of row q, cols 4p..4p+3.
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+}
+
+// XCD-aware block remap (bijective for any grid): blocks b, b+8 share an XCD under round-robin
+// dispatch, so give each XCD a contiguous run of tile ids (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

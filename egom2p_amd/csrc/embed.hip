@@ -1,0 +1,322 @@
+// Front end of the EgoM2P hot path on gfx950: mask compaction (stable partition by prefix sum),
+// fused token/positional/modality embedding gather, loss-row permutation, and the embedding backward.
+//
+// Replaces (reference egom2p/models/egom2p_model.py):
+//   cat_encoder_tensors :251-283, forward_mask_encoder :344-396  (argsort(mask + arange*1e-6) -> gather x4)
+//   cat_decoder_tensors :285-342, forward_mask_decoder :398-444, adapt_decoder_attention_mask :446-481
+//   encoder/decoder embedding modules (encoder_embeddings.py:181-210,272-301; decoder_embeddings.py:337-370,455-487)
+// Only the N (M) kept rows are ever embedded; the (B,T,D) tensors of the reference never exist.
+// Integer outputs are bit-exact with the reference; float rows are exact fp32 sums in the same order
+// (token + (pos + mod)).
+#include "common.h"
+#include "egom2p_hip.h"
+
+namespace {
+
+struct CompactArgs {
+    const unsigned char* mask[EGO_MAX_MODS];   // [B, n_pos[m]]  (True = ignore)
+    const long long* ids[EGO_MAX_MODS];        // [B, n_pos[m]]
+    const int* dam[EGO_MAX_MODS];              // decoder_attention_mask [B, n_pos[m]] or null
+    int n_pos[EGO_MAX_MODS];
+    int mod_id[EGO_MAX_MODS];
+    int n_mods, T, n_keep, is_decoder;
+    long long* ids_keep;      // [B, n_keep]
+    unsigned char* pad;       // [B, n_keep]
+    short* mod_mask;          // [B, n_keep]  (-1 on pads)
+    int* slot;                // [B, n_keep]  modality slot in this ordering (-1 on pads)
+    int* local;               // [B, n_keep]  position inside the modality
+    int* tok;                 // [B, n_keep]  token id at the kept position (0 on pads)
+    int* ks; int* ke;         // [B, n_keep]  allowed key interval per row
+    int* n_valid;             // [B]
+    int* seg;                 // [B, n_mods, 2]  (start, count) of each slot's kept unmasked rows
+    int* err;                 // [1] set if the decoder mask is not one interval per row
+};
+
+// one workgroup per sample
+__global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
+    __shared__ int s_cnt[256], s_dam[256], s_mcnt[256], s_mdam[256];
+    __shared__ int s_segstart[EGO_MAX_MODS + 1], s_tot[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int per = (a.T + 255) / 256;
+    const int p0 = tid * per, p1 = min(a.T, p0 + per);
+
+    // modality offsets
+    int moff[EGO_MAX_MODS + 1];
+    moff[0] = 0;
+#pragma unroll
+    for (int m = 0; m < EGO_MAX_MODS; ++m) moff[m + 1] = moff[m] + (m < a.n_mods ? a.n_pos[m] : 0);
+
+    auto locate = [&](int pos, int& m, int& loc) {
+        m = 0;
+#pragma unroll
+        for (int k = 1; k < EGO_MAX_MODS; ++k) if (k < a.n_mods && pos >= moff[k]) m = k;
+        loc = pos - moff[m];
+    };
+
+    // pass 1: counts of unmasked positions (and their dam sums) in this thread's range
+    if (tid < EGO_MAX_MODS) s_mcnt[tid] = 0;
+    __syncthreads();
+    int cnt = 0, dsum = 0, mdsum = 0, cur_m = -1, cur_c = 0;
+    for (int pos = p0; pos < p1; ++pos) {
+        int m, loc; locate(pos, m, loc);
+        const bool masked = a.mask[m][(long)b * a.n_pos[m] + loc] != 0;
+        const int d = (a.is_decoder && a.dam[m]) ? a.dam[m][(long)b * a.n_pos[m] + loc] : 0;
+        if (m != cur_m) { if (cur_c) atomicAdd(&s_mcnt[cur_m], cur_c); cur_m = m; cur_c = 0; }
+        if (!masked) { cnt++; cur_c++; dsum += d; } else { mdsum += d; }
+    }
+    if (cur_c) atomicAdd(&s_mcnt[cur_m], cur_c);
+    s_cnt[tid] = cnt; s_dam[tid] = dsum; s_mdam[tid] = mdsum;
+    __syncthreads();
+    // exclusive scans by thread 0..255 (256 values: a serial scan by one wave is plenty here)
+    if (tid == 0) {
+        int c = 0, d = 0, md = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int tc = s_cnt[i], td = s_dam[i], tmd = s_mdam[i];
+            s_cnt[i] = c; s_dam[i] = d; s_mdam[i] = md;
+            c += tc; d += td; md += tmd;
+        }
+        s_tot[0] = c; s_tot[1] = d;
+        // per-slot segment starts among the unmasked rows need per-modality counts: done below
+    }
+    __syncthreads();
+    const int total_valid = s_tot[0], total_dam = s_tot[1];
+    const int nv = min(total_valid, a.n_keep);
+    if (tid == 0) a.n_valid[b] = nv;
+
+    // per-modality unmasked counts (s_mcnt) -> segment (start,count) clipped to n_keep
+    if (tid == 0) {
+        int st = 0;
+        for (int m = 0; m < a.n_mods; ++m) {
+            s_segstart[m] = st;
+            const int s0 = min(st, a.n_keep), s1 = min(st + s_mcnt[m], a.n_keep);
+            a.seg[((long)b * a.n_mods + m) * 2] = s0;
+            a.seg[((long)b * a.n_mods + m) * 2 + 1] = s1 - s0;
+            st += s_mcnt[m];
+        }
+        s_segstart[a.n_mods] = st;
+    }
+    __syncthreads();
+
+    // pass 2: scatter
+    int uidx = s_cnt[tid];             // rank among unmasked
+    int dcum = s_dam[tid];             // dam prefix among unmasked (exclusive)
+    int mdcum = s_mdam[tid];           // dam prefix among masked (exclusive)
+    for (int pos = p0; pos < p1; ++pos) {
+        int m, loc; locate(pos, m, loc);
+        const long src = (long)b * a.n_pos[m] + loc;
+        const bool masked = a.mask[m][src] != 0;
+        const int d = (a.is_decoder && a.dam[m]) ? a.dam[m][src] : 0;
+        int out, cs;
+        if (!masked) { out = uidx++; dcum += d; cs = dcum; }
+        else { out = total_valid + (pos - uidx); mdcum += d; cs = total_dam + mdcum; }
+        if (out < a.n_keep) {
+            const long o = (long)b * a.n_keep + out;
+            a.ids_keep[o] = pos;
+            a.pad[o] = masked ? 1 : 0;
+            a.mod_mask[o] = masked ? (short)-1 : (short)a.mod_id[m];
+            a.slot[o] = masked ? -1 : m;
+            a.local[o] = loc;
+            a.tok[o] = masked ? 0 : (int)a.ids[m][src];
+            if (a.is_decoder) {
+                // allowed keys: same modality (ids compared before pads become -1) and j < cumsum(dam)_i.
+                // Same-modality unmasked keys are the contiguous segment [s0, s1).
+                const int s0 = min(s_segstart[m], a.n_keep), s1 = min(s_segstart[m] + s_mcnt[m], a.n_keep);
+                a.ks[o] = s0;
+                a.ke[o] = min(s1, cs);
+                if (cs > nv && nv < a.n_keep) atomicOr(a.err, 1);   // a pad key would be visible: not an interval mask
+            } else {
+                a.ks[o] = 0;
+                a.ke[o] = nv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather: one wave per kept row
+// ---------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const float* table[EGO_MAX_MODS];   // token tables [V, D] or null (decoder: rows are the mask token)
+    const float* pos[EGO_MAX_MODS];     // [n_pos, D]
+    const float* mod[EGO_MAX_MODS];     // [D]
+    const float* base_vec;              // mask_token [D] or null
+    const int* slot; const int* local; const int* tok;
+    float* x; float* emb;               // [rows, D]; emb may be null
+    long rows; int D;
+};
+
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= a.rows) return;
+    const int s = a.slot[row];
+    float* xr = a.x + row * a.D;
+    float* er = a.emb ? a.emb + row * a.D : nullptr;
+    const int nc = a.D >> 2;
+    if (s < 0) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < nc; c += 64) { *(f32x4*)(xr + c * 4) = z; if (er) *(f32x4*)(er + c * 4) = z; }
+        return;
+    }
+    const float *tb = nullptr, *ps = nullptr, *md = nullptr;
+#pragma unroll
+    for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) { tb = a.table[m]; ps = a.pos[m]; md = a.mod[m]; }
+    const float* tr = tb ? tb + (long)a.tok[row] * a.D : a.base_vec;
+    const float* pr = ps + (long)a.local[row] * a.D;
+    for (int c = lane; c < nc; c += 64) {
+        const f32x4 e = *(const f32x4*)(pr + c * 4) + *(const f32x4*)(md + c * 4);
+        const f32x4 t = *(const f32x4*)(tr + c * 4);
+        *(f32x4*)(xr + c * 4) = t + e;
+        if (er) *(f32x4*)(er + c * 4) = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss-row permutation: decoder rows grouped by modality (canonical order), (b, i) row-major inside,
+// exactly the row order of y[decoder_mod_mask == id] (egom2p_model.py:633).  One workgroup.
+//   seg   [B, n_mods, 2]  (start,count) per *decoder-order* slot
+//   canon [n_mods]        decoder slot -> canonical modality index
+//   perm  [B*M]           row -> grouped row (-1 for pads);  tgt_perm[grouped row] = target id
+//   ranges[n_mods, 2]     (offset, count) of each canonical modality in the grouped order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_perm_kernel(const int* __restrict__ seg, const int* __restrict__ canon,
+                                                        const int* __restrict__ slot, const int* __restrict__ tok,
+                                                        int B, int M, int n_mods, int* __restrict__ perm,
+                                                        int* __restrict__ tgt_perm, int* __restrict__ ranges,
+                                                        int* __restrict__ base /* [B, n_mods] scratch */) {
+    __shared__ int s_off[EGO_MAX_MODS + 1];
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < n_mods; ++c) {          // canonical modality c
+            int sl = 0;
+            for (int s = 0; s < n_mods; ++s) if (canon[s] == c) sl = s;
+            ranges[2 * c] = run;
+            for (int b = 0; b < B; ++b) {
+                base[b * n_mods + sl] = run;
+                run += seg[(b * n_mods + sl) * 2 + 1];
+            }
+            ranges[2 * c + 1] = run - ranges[2 * c];
+        }
+        s_off[0] = run;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const long total = (long)B * M;
+    for (long r = threadIdx.x; r < total; r += 256) {
+        const int s = slot[r];
+        if (s < 0) { perm[r] = -1; continue; }
+        const int b = (int)(r / M), i = (int)(r % M);
+        const int g = base[b * n_mods + s] + (i - seg[(b * n_mods + s) * 2]);
+        perm[r] = g;
+        tgt_perm[g] = tok[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding backward: table[slot][tok] += dx row ; dmod[slot] += (dx + d2) row ; dbase += dx row.
+// 64 rows per workgroup; modality sums are combined in LDS, then one atomic per column per workgroup.
+// ---------------------------------------------------------------------------------------------
+struct EmbedBwdArgs {
+    float* dtable[EGO_MAX_MODS];   // [V, D] grads or null
+    float* dmod[EGO_MAX_MODS];     // [D]
+    float* dbase;                  // [D] mask-token grad or null
+    const float* dx; const float* d2;   // [rows, D]; d2 may be null
+    const int* slot; const int* tok;
+    long rows; int D, n_mods;
+};
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lsum[];   // [(n_mods + 1)][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nsl = a.n_mods + 1;
+    for (int i = threadIdx.x; i < nsl * a.D; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+    for (int rr = 0; rr < 16; ++rr) {
+        const long row = (long)blockIdx.x * 64 + rr * 4 + wave;
+        if (row >= a.rows) break;
+        const int s = a.slot[row];
+        if (s < 0) continue;
+        float* trow = nullptr;
+#pragma unroll
+        for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) trow = a.dtable[m];
+        if (trow) trow += (long)a.tok[row] * a.D;
+        // one dword per lane, 256 contiguous bytes per wave instruction: the shape global float
+        // atomics run at full rate with
+        for (int col = lane; col < a.D; col += 64) {
+            float g = a.dx[row * a.D + col];
+            if (trow) atomicAdd(trow + col, g);
+            if (a.dbase) atomicAdd(&lsum[a.n_mods * a.D + col], g);
+            if (a.d2) g += a.d2[row * a.D + col];
+            atomicAdd(&lsum[s * a.D + col], g);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nsl * a.D; i += 256) {
+        const int s = i / a.D, col = i % a.D;
+        const float v = lsum[i];
+        if (v == 0.f) continue;
+        float* dst = nullptr;
+        if (s == a.n_mods) dst = a.dbase;
+        else {
+#pragma unroll
+            for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) dst = a.dmod[m];
+        }
+        if (dst) atomicAdd(dst + col, v);
+    }
+}
+
+}  // namespace
+
+extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream) {
+    if (!d || d->n_mods <= 0 || d->n_mods > EGO_MAX_MODS || B <= 0) return EGO_ERR_ARG;
+    CompactArgs a{};
+    int T = 0;
+    for (int m = 0; m < d->n_mods; ++m) {
+        a.mask[m] = (const unsigned char*)d->mask[m];
+        a.ids[m] = (const long long*)d->ids[m];
+        a.dam[m] = d->dam[m];
+        a.n_pos[m] = d->n_pos[m];
+        a.mod_id[m] = d->mod_id[m];
+        T += d->n_pos[m];
+    }
+    if (d->n_keep <= 0 || d->n_keep > T) return EGO_ERR_ARG;
+    a.n_mods = d->n_mods; a.T = T; a.n_keep = d->n_keep; a.is_decoder = d->is_decoder;
+    a.ids_keep = (long long*)d->ids_keep; a.pad = (unsigned char*)d->pad; a.mod_mask = (short*)d->mod_mask;
+    a.slot = d->slot; a.local = d->local; a.tok = d->tok; a.ks = d->ks; a.ke = d->ke;
+    a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err;
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream) {
+    if (!d || d->rows <= 0 || d->D % 4) return EGO_ERR_ARG;
+    EmbedArgs a{};
+    for (int m = 0; m < EGO_MAX_MODS; ++m) { a.table[m] = d->table[m]; a.pos[m] = d->pos[m]; a.mod[m] = d->mod[m]; }
+    a.base_vec = d->base_vec; a.slot = d->slot; a.local = d->local; a.tok = d->tok;
+    a.x = d->x; a.emb = d->emb; a.rows = d->rows; a.D = d->D;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* tok, int B, int M,
+                             int n_mods, int* perm, int* tgt_perm, int* ranges, int* base, hipStream_t stream) {
+    if (B <= 0 || M <= 0 || n_mods <= 0 || n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(loss_perm_kernel, dim3(1), dim3(256), 0, stream, seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
+    if (!d || d->rows <= 0 || d->D % 4 || d->n_mods <= 0 || d->n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
+    EmbedBwdArgs a{};
+    for (int m = 0; m < EGO_MAX_MODS; ++m) { a.dtable[m] = d->dtable[m]; a.dmod[m] = d->dmod[m]; }
+    a.dbase = d->dbase; a.dx = d->dx; a.d2 = d->d2; a.slot = d->slot; a.tok = d->tok;
+    a.rows = d->rows; a.D = d->D; a.n_mods = d->n_mods;
+    const size_t lds = (size_t)(d->n_mods + 1) * d->D * sizeof(float);
+    if (lds > 64 * 1024) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((d->rows + 63) / 64)), dim3(256), lds, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}

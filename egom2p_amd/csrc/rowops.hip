@@ -1,0 +1,422 @@
+// HBM-bound row kernels of the EgoM2P hot path (gfx950): bias-free LayerNorm fwd/bwd, SwiGLU
+// gate fwd/bwd, weight casts (fp32 master -> bf16 W and W^T), cross-entropy fwd/bwd over bf16
+// logits, bias gradient.  One wave (64 lanes) per row, 16-byte accesses, fp32 math.
+//
+// Reference sites: LayerNorm egom2p/models/egom2p_utils.py:118-133 (F.layer_norm, eps 1e-6, zero bias
+// buffer); GatedMlp :167-169; F.cross_entropy(reduction='mean') egom2p/models/egom2p_model.py:633-644.
+#include "common.h"
+#include "egom2p_hip.h"
+
+namespace {
+
+constexpr int LN_MAXC_MAX = 8;   // float4 chunks per lane -> D <= 2048 (kernels are instantiated for 3, 4, 6, 8)
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward: y(bf16) = (x - mean) * rstd * w ; optional output row permutation
+// ---------------------------------------------------------------------------------------------
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, const int* __restrict__ out_row,
+                                                     int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nc = D >> 2;
+    const float* xr = x + (long)row * D;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) { v[i] = *(const f32x4*)(xr + c * 4); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const int orow = out_row ? out_row[row] : row;
+    if (orow < 0) return;
+    bf16_t* yr = y + (long)orow * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            const f32x4 ww = *(const f32x4*)(w + c * 4);
+            u32x2 o = {pack_bf16x2((v[i][0] - mean) * rstd * ww[0], (v[i][1] - mean) * rstd * ww[1]),
+                       pack_bf16x2((v[i][2] - mean) * rstd * ww[2], (v[i][3] - mean) * rstd * ww[3])};
+            *(u32x2*)(yr + c * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx_out = (dx_in ? dx_in : 0) + rstd * (g - mean(g) - xhat * mean(g*xhat)),
+// g = dy * w; dw += sum_rows dy * xhat.  dy rows may be permuted (dy_row map, -1 = zero gradient).
+// Writes fp32 dx_out and an optional bf16 copy (the next GEMM's operand).
+// ---------------------------------------------------------------------------------------------
+constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wave)
+
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const int* __restrict__ dy_row,
+                                                     const float* __restrict__ x, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const float* __restrict__ w,
+                                                     const float* dx_in, float* dx_out, bf16_t* dx_bf16,
+                                                     float* __restrict__ dw, int rows, int D) {
+    __shared__ float red[4][LN_MAXC * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = D >> 2;
+    f32x4 ww[LN_MAXC], dwa[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        dwa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ww[i] = (c < nc) ? *(const f32x4*)(w + c * 4) : dwa[i];
+    }
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
+        if (row >= rows) break;
+        const int grow = dy_row ? dy_row[row] : row;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float* xr = x + (long)row * D;
+        f32x4 g[LN_MAXC], xh[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                const f32x4 xv = *(const f32x4*)(xr + c * 4);
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                if (grow >= 0) {
+                    const u32x2 raw = *(const u32x2*)(dy + (long)grow * D + c * 4);
+                    d = f32x4{bf16_to_f32(raw[0] & 0xffff), bf16_to_f32(raw[0] >> 16), bf16_to_f32(raw[1] & 0xffff), bf16_to_f32(raw[1] >> 16)};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mean) * rstd;
+                    g[i][e] = d[e] * ww[i][e];
+                    dwa[i][e] += d[e] * xh[i][e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
+                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * D + c * 4);
+                *(f32x4*)(dx_out + (long)row * D + c * 4) = o;
+                if (dx_bf16) {
+                    u32x2 b = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *(u32x2*)(dx_bf16 + (long)row * D + c * 4) = b;
+                }
+            }
+        }
+    }
+    // combine the 4 waves' dw partials, one atomic per column per workgroup
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) *(f32x4*)(&red[wave][c * 4]) = dwa[i];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256)
+        atomicAdd(dw + col, red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SwiGLU gate.  ab[rows, 2F]: a = cols [0,F), b = cols [F,2F).  h = bf16(bf16(silu(a)) * b)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, bf16_t* __restrict__ hout, long rows, int F) {
+    const int fc = F >> 3;                      // 8-element chunks per row
+    const long total = rows * fc;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / fc; const int c = (int)(idx % fc) * 8;
+        const u32x4 a = *(const u32x4*)(ab + r * 2 * F + c);
+        const u32x4 b = *(const u32x4*)(ab + r * 2 * F + F + c);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf16_to_f32(a[e] & 0xffff), a1 = bf16_to_f32(a[e] >> 16);
+            const float b0 = bf16_to_f32(b[e] & 0xffff), b1 = bf16_to_f32(b[e] >> 16);
+            o[e] = pack_bf16x2(round_bf16(a0 * sigmoidf_(a0)) * b0, round_bf16(a1 * sigmoidf_(a1)) * b1);
+        }
+        *(u32x4*)(hout + r * F + c) = o;
+    }
+}
+
+// dab[rows,2F]: da = dh * b * s * (1 + a (1 - s)),  db = dh * silu(a)
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ ab, const bf16_t* __restrict__ dh,
+                                  bf16_t* __restrict__ dab, long rows, int F) {
+    const int fc = F >> 3;
+    const long total = rows * fc;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / fc; const int c = (int)(idx % fc) * 8;
+        const u32x4 a = *(const u32x4*)(ab + r * 2 * F + c);
+        const u32x4 b = *(const u32x4*)(ab + r * 2 * F + F + c);
+        const u32x4 g = *(const u32x4*)(dh + r * F + c);
+        u32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float av[2] = {bf16_to_f32(a[e] & 0xffff), bf16_to_f32(a[e] >> 16)};
+            float bv[2] = {bf16_to_f32(b[e] & 0xffff), bf16_to_f32(b[e] >> 16)};
+            float gv[2] = {bf16_to_f32(g[e] & 0xffff), bf16_to_f32(g[e] >> 16)};
+            float da[2], db[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float s = sigmoidf_(av[k]);
+                da[k] = gv[k] * bv[k] * s * (1.f + av[k] * (1.f - s));
+                db[k] = gv[k] * av[k] * s;
+            }
+            oa[e] = pack_bf16x2(da[0], da[1]);
+            ob[e] = pack_bf16x2(db[0], db[1]);
+        }
+        *(u32x4*)(dab + r * 2 * F + c) = oa;
+        *(u32x4*)(dab + r * 2 * F + F + c) = ob;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight cast: fp32 W[rows_src, cols] -> bf16 Wb[rows_dst(pad), ld_w] (rows >= rows_src zero) and
+// bf16 Wt[cols, ld_t] = W^T (columns >= rows_src zero up to rows_dst).  32x32 LDS transpose tiles.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_w_kernel(const float* __restrict__ W, int rows_src, int cols, long ld_src,
+                                                     bf16_t* __restrict__ Wb, long ld_w, bf16_t* __restrict__ Wt,
+                                                     long ld_t, int rows_dst) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows_src && c < cols) v = W[(long)r * ld_src + c];
+        tile[ty + 8 * i][tx] = v;
+        if (Wb && r < rows_dst && c < cols) Wb[(long)r * ld_w + c] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    if (Wt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;           // Wt[c][r]
+            if (c < cols && r < rows_dst) Wt[(long)c * ld_t + r] = f32_to_bf16(tile[tx][ty + 8 * i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-entropy over bf16 logits rows [row_off, row_off + n) of a [*, V] buffer (ld = V).
+// fwd: nll[row] = lse - logit[target]; lse[row] kept.  bwd (in place): logits <- (softmax - onehot) * coef,
+// coef = *gscale / (n_mods * n).  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ logits, long ld, int V,
+                                                     const int* __restrict__ targets, const int* __restrict__ range,
+                                                     float* __restrict__ lse_out, float* __restrict__ nll_out) {
+    __shared__ float red[8];
+    const int off = range[0], n = range[1];
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const long row = (long)off + r;
+    const bf16_t* lr = logits + row * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = -3.0e38f;
+    const int vc = V >> 3;
+    for (int c = threadIdx.x; c < vc; c += 256) {
+        const u32x4 a = *(const u32x4*)(lr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(bf16_to_f32(a[e] & 0xffff), bf16_to_f32(a[e] >> 16)));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int c = threadIdx.x; c < vc; c += 256) {
+        const u32x4 a = *(const u32x4*)(lr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __expf(bf16_to_f32(a[e] & 0xffff) - mx) + __expf(bf16_to_f32(a[e] >> 16) - mx);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lse = mx + __logf(red[4] + red[5] + red[6] + red[7]);
+        lse_out[row] = lse;
+        nll_out[row] = lse - bf16_to_f32(lr[targets[row]]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V,
+                                                     const int* __restrict__ targets, const int* __restrict__ range,
+                                                     const float* __restrict__ lse_in, const float* __restrict__ gscale,
+                                                     float inv_mods) {
+    const int off = range[0], n = range[1];
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const long row = (long)off + r;
+    bf16_t* lr = logits + row * ld;
+    const float lse = lse_in[row];
+    const float coef = gscale[0] * inv_mods / (float)n;
+    const int tgt = targets[row];
+    const int vc = V >> 3;
+    for (int c = threadIdx.x; c < vc; c += 256) {
+        const u32x4 a = *(const u32x4*)(lr + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i0 = c * 8 + 2 * e;
+            float p0 = __expf(bf16_to_f32(a[e] & 0xffff) - lse), p1 = __expf(bf16_to_f32(a[e] >> 16) - lse);
+            if (i0 == tgt) p0 -= 1.f;
+            if (i0 + 1 == tgt) p1 -= 1.f;
+            o[e] = pack_bf16x2(p0 * coef, p1 * coef);
+        }
+        *(u32x4*)(lr + c * 8) = o;
+    }
+}
+
+// mod_loss[m] = sum(nll[off..off+n)) / n (0 if n == 0); loss = sum_m mod_loss / n_mods.  One block.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ nll, const int* __restrict__ ranges,
+                                                            int n_mods, float* __restrict__ out) {
+    __shared__ float red[4];
+    float total = 0.f;
+    for (int m = 0; m < n_mods; ++m) {
+        const int off = ranges[2 * m], n = ranges[2 * m + 1];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += nll[off + i];
+        s = wave_sum(s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float ml = n > 0 ? (red[0] + red[1] + red[2] + red[3]) / (float)n : 0.f;
+        if (threadIdx.x == 0) out[1 + m] = ml;
+        total += ml;
+    }
+    if (threadIdx.x == 0) out[0] = total / (float)n_mods;
+}
+
+// db[col] += sum_rows g[row][col]   (bf16 g, fp32 accumulate)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ g, long rows, int D, float* __restrict__ db) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= D) return;
+    const long r0 = (long)blockIdx.y * 256, r1 = min(rows, r0 + 256);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += bf16_to_f32(g[r * D + col]);
+    atomicAdd(db + col, s);
+}
+
+// dst_bf16 = src_f32 (flat)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(src + i * 4);
+        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(dst + i * 4) = o;
+    }
+}
+
+inline int grid_for(long total, int cap = 4096) { return (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap); }
+
+}  // namespace
+
+extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd,
+                                 const int* out_row, int rows, int D, float eps, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
+#define LN_FWD(C) hipLaunchKernelGGL(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps)
+    if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else if (D <= 1536) LN_FWD(6); else LN_FWD(8);
+#undef LN_FWD
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float* x, const float* mean,
+                                 const float* rstd, const float* w, const float* dx_in, float* dx_out,
+                                 void* dx_bf16, float* dw, int rows, int D, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
+#define LN_BWD(C) hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, stream, (const bf16_t*)dy, \
+                       dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, dw, rows, D)
+    if (D <= 768) LN_BWD(3); else if (D <= 1024) LN_BWD(4); else if (D <= 1536) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    if (F % 8) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (bf16_t*)h, rows, F);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long rows, int F, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    if (F % 8) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (const bf16_t*)dh, (bf16_t*)dab, rows, F);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_cast_weight(const float* W, int rows, int cols, long ld_src, void* Wb, long ld_w, void* Wt, long ld_t,
+                               int rows_dst, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || rows_dst < rows) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(cast_w_kernel, dim3((cols + 31) / 32, (rows_dst + 31) / 32), dim3(256), 0, stream, W, rows, cols, ld_src,
+                       (bf16_t*)Wb, ld_w, (bf16_t*)Wt, ld_t, rows_dst);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+    if (n <= 0) return EGO_OK;
+    if (n % 4) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, src, (bf16_t*)dst, n / 4);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_ce_fwd(const void* logits, long ld, int V, const int* targets, const int* range, int max_rows,
+                          float* lse, float* nll, hipStream_t stream) {
+    if (max_rows <= 0) return EGO_OK;
+    if (V % 8 || ld % 8) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(max_rows), dim3(256), 0, stream, (const bf16_t*)logits, ld, V, targets, range, lse, nll);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows,
+                          const float* lse, const float* gscale, int n_mods, hipStream_t stream) {
+    if (max_rows <= 0) return EGO_OK;
+    if (V % 8 || ld % 8 || n_mods <= 0) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream) {
+    if (n_mods <= 0) return EGO_ERR_ARG;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, nll, ranges, n_mods, out);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((D + 255) / 256, (int)((rows + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)g, rows, D, db);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}

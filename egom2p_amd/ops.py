@@ -1,0 +1,176 @@
+"""Thin per-kernel wrappers: torch tensors are only containers (device memory + stream); every
+call goes straight to the C-ABI of libegom2p_hip.so.  Used by the engine and by the parity tests."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import check
+
+BF16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.EgoHipError("egom2p_amd ops need tensors on the GPU; there is no CPU fallback")
+
+
+# ------------------------------------------------------------------------------------------
+def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6):
+    _need_cuda(x)
+    rows, D = x.shape
+    check(L.load().ego_layernorm_fwd(_p(x), _p(w), _p(y), _p(mean), _p(rstd), _p(out_row), rows, D, eps, _stream()),
+          "ego_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
+    _need_cuda(x)
+    rows, D = x.shape
+    check(L.load().ego_layernorm_bwd(_p(dy), _p(dy_row), _p(x), _p(mean), _p(rstd), _p(w), _p(dx_in), _p(dx_out),
+                                     _p(dx_bf16), _p(dw), rows, D, _stream()), "ego_layernorm_bwd")
+
+
+def gemm_nt(A, B, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None, m_range=None, lda=None, ldb=None, ldc=None, ldr=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+ epilogue)."""
+    _need_cuda(A)
+    lda = A.stride(-2) if lda is None else lda
+    ldb = B.stride(-2) if ldb is None else ldb
+    ldc = C_out.stride(-2) if ldc is None else ldc
+    ldr = 0 if R is None else (R.stride(-2) if ldr is None else ldr)
+    check(L.load().ego_gemm_nt_bf16(_p(A), lda, _p(B), ldb, _p(C_out), ldc, _p(R), ldr, _p(bias), _p(m_range), M, N, K, epi,
+                                    _stream()), "ego_gemm_nt_bf16")
+
+
+def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_range=None, splits=1, slab=None,
+            ldp=None, ldq=None, ldc=None):
+    """C[Ni,Nj] += P[M,Ni]^T @ Q[M,Nj]."""
+    _need_cuda(P)
+    ldp = P.stride(-2) if ldp is None else ldp
+    ldq = Q.stride(-2) if ldq is None else ldq
+    ldc = C0.stride(-2) if ldc is None else ldc
+    if C1 is None:
+        split_row = Ni
+    rows0 = (split_row if rows0 is None else rows0)
+    check(L.load().ego_gemm_tn_bf16(_p(P), ldp, _p(Q), ldq, _p(C0), _p(C1), ldc, split_row, rows0, rows1, _p(m_range), Ni, Nj,
+                                    M, splits, _p(slab), _stream()), "ego_gemm_tn_bf16")
+
+
+def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):
+    check(L.load().ego_attn_fwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, _p(lse), _p(ks), _p(ke),
+                                    r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_fwd_d64")
+
+
+def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
+             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):
+    check(L.load().ego_attn_bwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs,
+                                    _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
+                                    _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_bwd_d64")
+
+
+def swiglu_fwd(ab, h, rows, F):
+    check(L.load().ego_swiglu_fwd(_p(ab), _p(h), rows, F, _stream()), "ego_swiglu_fwd")
+
+
+def swiglu_bwd(ab, dh, dab, rows, F):
+    check(L.load().ego_swiglu_bwd(_p(ab), _p(dh), _p(dab), rows, F, _stream()), "ego_swiglu_bwd")
+
+
+def ce_fwd(logits, ld, V, targets, rng, max_rows, lse, nll):
+    check(L.load().ego_ce_fwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(nll), _stream()), "ego_ce_fwd")
+
+
+def ce_bwd(logits, ld, V, targets, rng, max_rows, lse, gscale, n_mods):
+    check(L.load().ego_ce_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(gscale), n_mods, _stream()),
+          "ego_ce_bwd")
+
+
+def loss_finalize(nll, ranges, n_mods, out):
+    check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _stream()), "ego_loss_finalize")
+
+
+def cast_weight(W, Wb=None, Wt=None, rows_dst=None, ld_w=None, ld_t=None):
+    rows, cols = W.shape
+    rows_dst = rows if rows_dst is None else rows_dst
+    ld_w = cols if ld_w is None else ld_w
+    ld_t = rows_dst if ld_t is None else ld_t
+    check(L.load().ego_cast_weight(_p(W), rows, cols, W.stride(0), _p(Wb), ld_w, _p(Wt), ld_t, rows_dst, _stream()),
+          "ego_cast_weight")
+
+
+def cast_f32_bf16(src, dst):
+    check(L.load().ego_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "ego_cast_f32_bf16")
+
+
+def bias_grad(g, rows, D, db):
+    check(L.load().ego_bias_grad(_p(g), rows, D, _p(db), _stream()), "ego_bias_grad")
+
+
+def grad_sqnorm(g, out):
+    check(L.load().ego_grad_sqnorm(_p(g), g.numel(), _p(out), _stream()), "ego_grad_sqnorm")
+
+
+def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.95, eps=1e-8, gscale=1.0, max_norm=0.0, sqnorm=None,
+               zero_grad=False):
+    check(L.load().ego_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, wd, beta1, beta2, eps, step, gscale, max_norm,
+                                  _p(sqnorm), int(zero_grad), _stream()), "ego_adamw_step")
+
+
+def grad_scale(g, gscale, max_norm, sqnorm):
+    check(L.load().ego_grad_scale(_p(g), g.numel(), gscale, max_norm, _p(sqnorm), _stream()), "ego_grad_scale")
+
+
+def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_pos, mod_ids, n_keep, is_decoder, out, B):
+    """`out`: dict of preallocated tensors (ids_keep,pad,mod_mask,slot,local,tok,ks,ke,n_valid,seg,err)."""
+    d = L.CompactDesc()
+    d.n_mods, d.n_keep, d.is_decoder = len(masks), n_keep, int(is_decoder)
+    for i in range(len(masks)):
+        d.mask[i] = masks[i].data_ptr()
+        d.ids[i] = ids[i].data_ptr()
+        d.dam[i] = dams[i].data_ptr() if (dams is not None and dams[i] is not None) else None
+        d.n_pos[i] = n_pos[i]
+        d.mod_id[i] = mod_ids[i]
+    for k in ("ids_keep", "pad", "mod_mask", "slot", "local", "tok", "ks", "ke", "n_valid", "seg", "err"):
+        setattr(d, k, out[k].data_ptr())
+    check(L.load().ego_compact(C.byref(d), B, _stream()), "ego_compact")
+
+
+def embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D):
+    d = L.EmbedDesc()
+    for i in range(len(pos)):
+        d.table[i] = None if tables is None or tables[i] is None else tables[i].data_ptr()
+        d.pos[i] = pos[i].data_ptr()
+        d.mod[i] = mod[i].data_ptr()
+    d.base_vec = _p(base_vec)
+    d.slot, d.local, d.tok = slot.data_ptr(), local.data_ptr(), tok.data_ptr()
+    d.x, d.emb = x.data_ptr(), _p(emb)
+    d.rows, d.D = rows, D
+    check(L.load().ego_embed_fwd(C.byref(d), _stream()), "ego_embed_fwd")
+
+
+def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D):
+    d = L.EmbedBwdDesc()
+    for i in range(len(dmods)):
+        d.dtable[i] = None if dtables is None or dtables[i] is None else dtables[i].data_ptr()
+        d.dmod[i] = dmods[i].data_ptr()
+    d.dbase = _p(dbase)
+    d.dx, d.d2 = dx.data_ptr(), _p(d2)
+    d.slot, d.tok = slot.data_ptr(), tok.data_ptr()
+    d.rows, d.D, d.n_mods = rows, D, len(dmods)
+    check(L.load().ego_embed_bwd(C.byref(d), _stream()), "ego_embed_bwd")
+
+
+def loss_perm(seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base):
+    check(L.load().ego_loss_perm(_p(seg), _p(canon), _p(slot), _p(tok), B, M, n_mods, _p(perm), _p(tgt_perm), _p(ranges),
+                                 _p(base), _stream()), "ego_loss_perm")

@@ -1,0 +1,161 @@
+/* C-ABI of libegom2p_hip.so - the MI355X (gfx950) engine under the EgoM2P Python surface.
+ *
+ * The reference (lgen-sudo/EgoM2P) is pure PyTorch and has no FFI; its drop-in boundary is the
+ * nn.Module surface of `EgoM2P` (egom2p/models/egom2p_model.py:57-734).  These entry points are what
+ * sits under that surface here: plain C functions over raw device pointers, explicit shapes/strides
+ * and a hipStream_t.  They return 0 on success (EGO_ERR_ARG = rejected arguments, EGO_ERR_LAUNCH =
+ * launch failed), never allocate caller-visible memory, never synchronise, and keep no global state,
+ * so every call is capturable in a hipGraph and re-entrant per stream.
+ *
+ * Each declaration cites the reference code it replaces (paths relative to the reference root).
+ * All "bf16" pointers are raw 16-bit bfloat16; "row-major [R, C] with ld" means element (r, c) at
+ * base + r * ld + c.
+ */
+#ifndef EGOM2P_HIP_H
+#define EGOM2P_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGO_ABI_VERSION 1
+#define EGO_MAX_MODS 8
+
+/* GEMM epilogues */
+#define EGO_EPI_BF16 0        /* C(bf16) = acc                                            */
+#define EGO_EPI_F32 1         /* C(f32)  = acc                                            */
+#define EGO_EPI_RESID 2       /* C(f32)  = R(f32) + bf16(acc)        residual add         */
+#define EGO_EPI_BIAS_RESID 3  /* C(f32)  = R(f32) + bf16(acc + bias) context projection   */
+
+int ego_abi_version(void);
+
+/* ---- front end ------------------------------------------------------------------------------- */
+
+/* Stable-partition compaction of one side (encoder inputs / decoder targets) of a clip batch.
+ * Replaces cat_encoder_tensors + forward_mask_encoder (egom2p/models/egom2p_model.py:251-283, 344-396)
+ * and cat_decoder_tensors + forward_mask_decoder + adapt_decoder_attention_mask (:285-342, 398-481).
+ * Modalities are given in concatenation order (decoder: the shuffled order of :312). */
+typedef struct {
+    int n_mods, n_keep, is_decoder;
+    const void* mask[EGO_MAX_MODS];  /* uint8/bool [B, n_pos[m]], nonzero = ignore                       */
+    const void* ids[EGO_MAX_MODS];   /* int64 [B, n_pos[m]] token ids                                     */
+    const int* dam[EGO_MAX_MODS];    /* int32 [B, n_pos[m]] decoder_attention_mask (decoder only, or NULL)*/
+    int n_pos[EGO_MAX_MODS];
+    int mod_id[EGO_MAX_MODS];        /* sha256-derived modality ids (egom2p/utils/misc.py:39-41)          */
+    void* ids_keep;                  /* out int64 [B, n_keep]                                             */
+    void* pad;                       /* out uint8 [B, n_keep] 1 = padding row                             */
+    void* mod_mask;                  /* out int16 [B, n_keep] modality id, -1 on padding                  */
+    int* slot;                       /* out int32 [B, n_keep] modality slot, -1 on padding                */
+    int* local;                      /* out int32 [B, n_keep] position inside the modality                */
+    int* tok;                        /* out int32 [B, n_keep] token id (decoder: target id), 0 on padding */
+    int* ks; int* ke;                /* out int32 [B, n_keep] allowed attention key interval per row      */
+    int* n_valid;                    /* out int32 [B]                                                     */
+    int* seg;                        /* out int32 [B, n_mods, 2] (start, count) of each slot's kept rows  */
+    int* err;                        /* in/out int32 [1]: |= 1 if the decoder mask is not an interval     */
+} ego_compact_desc;
+int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream);
+
+/* Fused embedding of the kept rows: x = token_row + (pos_row + mod_emb), emb = pos_row + mod_emb;
+ * padding rows are zero.  Replaces the embedding modules' forward (encoder_embeddings.py:181-210,
+ * 272-301; decoder_embeddings.py:337-370, 455-487) + torch.gather x2 + masked zeroing
+ * (egom2p_model.py:375-391, 427-438, 718, 723).  Decoder: table[] NULL and base_vec = mask_token (:328). */
+typedef struct {
+    const float* table[EGO_MAX_MODS];
+    const float* pos[EGO_MAX_MODS];
+    const float* mod[EGO_MAX_MODS];
+    const float* base_vec;
+    const int* slot; const int* local; const int* tok;
+    float* x; float* emb;
+    long rows; int D;
+} ego_embed_desc;
+int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream);
+
+/* Backward of the above: embedding_dense_backward scatter-add + mod_emb / mask_token reductions. */
+typedef struct {
+    float* dtable[EGO_MAX_MODS];
+    float* dmod[EGO_MAX_MODS];
+    float* dbase;
+    const float* dx; const float* d2;
+    const int* slot; const int* tok;
+    long rows; int D, n_mods;
+} ego_embed_bwd_desc;
+int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream);
+
+/* Row order of `y[decoder_mod_mask == id]` for every modality (egom2p_model.py:633): perm[row] = row
+ * in the modality-grouped order (-1 for padding), targets gathered alongside, (offset,count) per
+ * modality in `ranges`.  `base` is int32 [B, n_mods] scratch. */
+int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* tok, int B, int M, int n_mods,
+                  int* perm, int* tgt_perm, int* ranges, int* base, hipStream_t stream);
+
+/* ---- transformer blocks ---------------------------------------------------------------------- */
+
+/* Bias-free LayerNorm (egom2p/models/egom2p_utils.py:118-133): y(bf16)[out_row[r]] = LN(x[r]) * w.
+ * out_row may be NULL (identity); -1 drops the row. mean/rstd are saved for the backward. */
+int ego_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* mean, float* rstd, const int* out_row,
+                      int rows, int D, float eps, hipStream_t stream);
+/* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row. */
+int ego_layernorm_bwd(const void* dy_bf16, const int* dy_row, const float* x, const float* mean, const float* rstd,
+                      const float* w, const float* dx_in, float* dx_out, void* dx_out_bf16, float* dw, int rows, int D,
+                      hipStream_t stream);
+
+/* C[M,N] = A[M,K] . B[N,K]^T, bf16 inputs, fp32 MFMA accumulate.  Replaces F.linear under
+ * autocast(bf16) (egom2p_utils.py:141-169, 180-203, 215-242; decoder_embeddings.py:372-383, 489-500)
+ * and its dgrad (B = W^T).  m_range: optional device int[2] = {row offset, row count}; then M is an
+ * upper bound for the grid and A/C/R rows start at the offset. */
+int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* R, long ldr,
+                     const float* bias, const int* m_range, int M, int N, int K, int epi, hipStream_t stream);
+/* C[Ni,Nj] += P[M,Ni]^T . Q[M,Nj] (wgrad).  Output rows [0,split_row) go to C0 (first rows0 valid),
+ * rows >= split_row to C1 (first rows1 valid) - lets fused/padded weights scatter to their own grads.
+ * splits > 1: deterministic split over M through `slab` (fp32 [splits, Ni, Nj]). */
+int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C0, float* C1, long ldc, int split_row,
+                     int rows0, int rows1, const int* m_range, int Ni, int Nj, int M, int splits, float* slab,
+                     hipStream_t stream);
+
+/* Fused attention, head_dim 64 (Attention / CrossAttention, egom2p_utils.py:185-205, 222-244).
+ * Element (b, row, head h, d) of X at X + b * x_bs + row * x_rs + h * 64 + d.  ks/ke: allowed key
+ * interval of query row (b, q) at [b * r_bs + q * r_rs] (r_rs = 0: one interval per sample).
+ * LSE: fp32 [B, H, Nq], log2 domain. */
+int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                     long v_rs, void* O, long o_bs, long o_rs, float* LSE, const int* ks, const int* ke, long r_bs,
+                     long r_rs, int B, int H, int Nq, int Nk, float scale, hipStream_t stream);
+int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                     long v_rs, const void* O, long o_bs, long o_rs, const void* dO, long do_bs, long do_rs,
+                     const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
+                     void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
+                     int Nq, int Nk, float scale, hipStream_t stream);
+
+/* SwiGLU gate on the fused fc1||fc3 output ab[rows, 2F] (GatedMlp, egom2p_utils.py:167-169). */
+int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream);
+int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long rows, int F, hipStream_t stream);
+
+/* ---- loss head ------------------------------------------------------------------------------- */
+
+/* F.cross_entropy(reduction='mean') per modality over bf16 logits rows [range[0], range[0]+range[1])
+ * (egom2p_model.py:633-644).  bwd overwrites the logits with d loss / d logits (bf16). */
+int ego_ce_fwd(const void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse,
+               float* nll, hipStream_t stream);
+int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, const float* lse,
+               const float* gscale, int n_mods, hipStream_t stream);
+/* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality. */
+int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream);
+
+/* ---- parameters / optimiser ------------------------------------------------------------------ */
+
+/* fp32 master W[rows, cols] -> bf16 W (zero-padded to rows_dst rows) and/or bf16 W^T [cols, rows_dst]. */
+int ego_cast_weight(const float* W, int rows, int cols, long ld_src, void* Wb, long ld_w, void* Wt, long ld_t,
+                    int rows_dst, hipStream_t stream);
+int ego_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
+int ego_bias_grad(const void* g_bf16, long rows, int D, float* db, hipStream_t stream);
+
+/* clip_grad_norm_ + AdamW over flat buffers (egom2p/utils/native_scaler.py:28-43, optim_factory.py:226). */
+int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t stream);
+int ego_adamw_step(float* p, float* g, float* m, float* v, long n, float lr, float wd, float beta1, float beta2, float eps,
+                   int step, float gscale, float max_norm, const double* sqnorm, int zero_grad, hipStream_t stream);
+int ego_grad_scale(float* g, long n, float gscale, float max_norm, const double* sqnorm, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""Front-end parity on the GPU: compaction / embedding gather / loss permutation / embedding backward
+through the C-ABI against the CPU oracle (integer outputs bit-exact, fp32 rows exact)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from egom2p_amd import ops, synth  # noqa: E402
+from egom2p_amd.config import MODEL_CFGS  # noqa: E402
+from egom2p_amd.posemb import build_pos_emb  # noqa: E402
+from oracle import egom2p_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _alloc(B, n_keep, n_mods):
+    i32 = dict(device=DEV, dtype=torch.int32)
+    return dict(ids_keep=torch.full((B, n_keep), -7, device=DEV, dtype=torch.int64),
+                pad=torch.full((B, n_keep), 9, device=DEV, dtype=torch.uint8),
+                mod_mask=torch.full((B, n_keep), 99, device=DEV, dtype=torch.int16),
+                slot=torch.full((B, n_keep), 99, **i32), local=torch.full((B, n_keep), -9, **i32),
+                tok=torch.full((B, n_keep), -9, **i32), ks=torch.full((B, n_keep), -9, **i32),
+                ke=torch.full((B, n_keep), -9, **i32), n_valid=torch.zeros(B, **i32),
+                seg=torch.zeros(B, n_mods, 2, **i32), err=torch.zeros(1, **i32))
+
+
+def _run_compact(cfg, md, mods, n_keep, is_decoder):
+    B = md[mods[0].name]["input_mask"].shape[0]
+    key = "target_mask" if is_decoder else "input_mask"
+    masks = [md[m.name][key].to(DEV).contiguous() for m in mods]
+    ids = [md[m.name]["tensor"].reshape(B, -1).to(DEV).contiguous() for m in mods]
+    dams = [md[m.name]["decoder_attention_mask"].to(DEV).contiguous() for m in mods] if is_decoder else None
+    out = _alloc(B, n_keep, len(mods))
+    ops.compact(masks, ids, dams, [m.max_tokens for m in mods], [m.id for m in mods], n_keep, is_decoder, out, B)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("cfg_name,B,n,budgets", [
+    ("ego_tiny_2e_2d", 4, 32, {"tok_cam": [(10, 12), (3, 0), (15, 15), (0, 7)], "tok_gaze": [(9, 5), (20, 10), (1, 29), (16, 0)]}),
+    ("ego_b_2e_2d", 3, 2048, None),
+    ("ego_b_2e_2d", 4, 2048, "dirichlet"),
+    ("ego_b_2e_2d", 2, 700, None),          # truncation: more valid tokens than kept
+])
+def test_compact_bit_exact(cfg_name, B, n, budgets):
+    cfg = MODEL_CFGS[cfg_name]
+    if budgets == "dirichlet":
+        budgets = synth.dirichlet_budgets(cfg, B, n, n, seed=7)
+    md = synth.make_clip_batch(cfg, B, budgets, seed=7)
+    mods = cfg.mods
+    # encoder side
+    out = _run_compact(cfg, md, mods, n, False)
+    ce = O.compact_encoder(md, mods, n)
+    assert np.array_equal(out["ids_keep"].cpu().numpy(), ce["ids_keep"])
+    assert np.array_equal(out["pad"].cpu().numpy().astype(bool), ce["pad"])
+    assert np.array_equal(out["mod_mask"].cpu().numpy(), ce["mod_mask"])
+    valid = ~ce["pad"]
+    assert np.array_equal(out["tok"].cpu().numpy()[valid], ce["tok"][valid])
+    assert np.array_equal(out["local"].cpu().numpy()[valid], ce["local"][valid])
+    assert np.array_equal(out["slot"].cpu().numpy()[valid], ce["slot"][valid])
+    assert np.array_equal(out["n_valid"].cpu().numpy(), valid.sum(1))
+    assert (out["ks"].cpu().numpy() == 0).all()
+    assert np.array_equal(out["ke"].cpu().numpy(), np.repeat(valid.sum(1)[:, None], n, 1))
+    # decoder side, shuffled modality order
+    order = list(reversed(mods)) if len(mods) == 2 else [mods[2], mods[0], mods[3], mods[1]]
+    out = _run_compact(cfg, md, order, n, True)
+    cd = O.compact_decoder(md, order, n)
+    assert np.array_equal(out["ids_keep"].cpu().numpy(), cd["ids_keep"])
+    assert np.array_equal(out["pad"].cpu().numpy().astype(bool), cd["pad"])
+    assert np.array_equal(out["mod_mask"].cpu().numpy(), cd["mod_mask"])
+    assert np.array_equal(out["tok"].cpu().numpy(), cd["target_ids"])
+    ks, ke, ok = O.attention_ranges(cd["dam"], cd["mod_mask_pre"], cd["pad"])
+    assert ok and out["err"].item() == 0
+    gks, gke = out["ks"].cpu().numpy(), out["ke"].cpu().numpy()
+    nonempty = ke > ks
+    assert np.array_equal(gks[nonempty], ks[nonempty]) and np.array_equal(gke[nonempty], ke[nonempty])
+    assert (gke[~nonempty] <= gks[~nonempty]).all()
+
+
+def test_embed_and_backward_and_perm():
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    B, n = 3, 512
+    budgets = synth.dirichlet_budgets(cfg, B, n, n, seed=3)
+    md = synth.make_clip_batch(cfg, B, budgets, seed=3)
+    mods = cfg.mods
+    D = cfg.dim
+    tables = [synth.normal(f"t{m.name}", (m.vocab_size, D), 0.02).to(DEV) for m in mods]
+    pos = [build_pos_emb(m, D)[0].to(DEV).contiguous() for m in mods]
+    modv = [synth.normal(f"m{m.name}", (D,), 0.02).to(DEV) for m in mods]
+    out = _run_compact(cfg, md, mods, n, False)
+    x = torch.empty(B * n, D, device=DEV)
+    emb = torch.empty(B * n, D, device=DEV)
+    ops.embed_fwd(tables, pos, modv, None, out["slot"], out["local"], out["tok"], x, emb, B * n, D)
+    slot = out["slot"].view(-1).long()
+    ref_e = torch.zeros(B * n, D, device=DEV)
+    ref_x = torch.zeros(B * n, D, device=DEV)
+    for i in range(len(mods)):
+        sel = slot == i
+        e = pos[i][out["local"].view(-1)[sel].long()] + modv[i]
+        ref_e[sel] = e
+        ref_x[sel] = tables[i][out["tok"].view(-1)[sel].long()] + e
+    assert torch.equal(emb, ref_e) and torch.equal(x, ref_x)
+
+    # backward: scatter-add into tables, modality sums, base vector
+    dx = torch.randn(B * n, D, device=DEV)
+    d2 = torch.randn(B * n, D, device=DEV)
+    dtab = [torch.zeros_like(t) for t in tables]
+    dmod = [torch.zeros(D, device=DEV) for _ in mods]
+    dbase = torch.zeros(D, device=DEV)
+    ops.embed_bwd(dtab, dmod, dbase, dx, d2, out["slot"], out["tok"], B * n, D)
+    for i in range(len(mods)):
+        sel = slot == i
+        ref_t = torch.zeros_like(tables[i]).index_add_(0, out["tok"].view(-1)[sel].long(), dx[sel])
+        assert (dtab[i] - ref_t).abs().max().item() < 1e-4
+        assert (dmod[i] - (dx[sel] + d2[sel]).sum(0)).abs().max().item() < 2e-3
+    assert (dbase - dx[slot >= 0].sum(0)).abs().max().item() < 2e-3
+
+    # loss permutation on the decoder side
+    order = [mods[2], mods[0], mods[3], mods[1]]
+    outd = _run_compact(cfg, md, order, n, True)
+    canon = torch.tensor([mods.index(m) for m in order], device=DEV, dtype=torch.int32)
+    perm = torch.empty(B * n, device=DEV, dtype=torch.int32)
+    tperm = torch.full((B * n,), -1, device=DEV, dtype=torch.int32)
+    ranges = torch.zeros(len(mods), 2, device=DEV, dtype=torch.int32)
+    base = torch.zeros(B, len(mods), device=DEV, dtype=torch.int32)
+    ops.loss_perm(outd["seg"], canon, outd["slot"], outd["tok"], B, n, len(mods), perm, tperm, ranges, base)
+    mm = outd["mod_mask"].view(-1).cpu().numpy()
+    tg = outd["tok"].view(-1).cpu().numpy()
+    p = perm.cpu().numpy()
+    off = 0
+    for c, m in enumerate(mods):
+        rows = np.flatnonzero(mm == m.id)                    # row order of y[decoder_mod_mask == id]
+        assert ranges[c, 0].item() == off and ranges[c, 1].item() == rows.size
+        assert np.array_equal(p[rows], off + np.arange(rows.size))
+        assert np.array_equal(tperm.cpu().numpy()[off:off + rows.size], tg[rows])
+        off += rows.size
+    assert (p[mm == -1] == -1).all()

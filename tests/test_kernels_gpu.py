@@ -1,0 +1,289 @@
+"""Per-kernel parity tests on a real MI355X: every C-ABI entry point against a plain PyTorch fp32
+reference of the same op (integer outputs bit-exact; float tolerances stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from egom2p_amd import _lib as L  # noqa: E402
+from egom2p_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    torch.manual_seed(1234)
+
+
+def test_library_loads():
+    assert L.load().ego_abi_version() == 1
+
+
+# ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4096, 768, 768), (2048, 2304, 768), (1000, 768, 2048), (120, 128, 384)])
+def test_gemm_nt_epilogues(M, N, K):
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    ref = A.float() @ B.float().t()
+    C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16)
+    assert _rel(C.float(), ref) < 4e-3
+    C32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(A, B, C32, M, N, K, L.EPI_F32)
+    assert _rel(C32, ref) < 1e-5
+    R = torch.randn(M, N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(A, B, out, M, N, K, L.EPI_RESID, R=R)
+    assert _rel(out, R + _bf(ref).float()) < 2e-3
+    bias = torch.randn(N, device=DEV)
+    ops.gemm_nt(A, B, out, M, N, K, L.EPI_BIAS_RESID, R=R, bias=bias)
+    assert _rel(out, R + _bf(ref + _bf(bias).float()).float()) < 2e-3
+
+
+def test_gemm_nt_row_range():
+    M, N, K = 1024, 256, 128
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    C = torch.full((M, N), 7.0, device=DEV)
+    rng = torch.tensor([130, 333], device=DEV, dtype=torch.int32)
+    ops.gemm_nt(A, B, C, M, N, K, L.EPI_F32, m_range=rng)
+    ref = A.float() @ B.float().t()
+    assert _rel(C[130:463], ref[130:463]) < 1e-5
+    assert (C[:130] == 7).all() and (C[463:] == 7).all()
+
+
+# ------------------------------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("M,Ni,Nj,splits", [(1000, 256, 128, 1), (4096, 768, 768, 4), (777, 2304, 768, 3), (64, 128, 128, 1)])
+def test_gemm_tn(M, Ni, Nj, splits):
+    P = _bf(torch.randn(M, Ni, device=DEV))
+    Q = _bf(torch.randn(M, Nj, device=DEV))
+    C0 = torch.randn(Ni, Nj, device=DEV)
+    ref = C0 + P.float().t() @ Q.float()
+    slab = torch.empty(splits, Ni, Nj, device=DEV) if splits > 1 else None
+    ops.gemm_tn(P, Q, C0, Ni, Nj, M, splits=splits, slab=slab)
+    assert _rel(C0, ref) < 1e-5
+
+
+def test_gemm_tn_split_rows_and_range():
+    M, Ni, Nj = 900, 256, 128           # fused/padded output: rows [0,128) -> C0 (100 valid), [128,256) -> C1 (90 valid)
+    P = _bf(torch.randn(M, Ni, device=DEV))
+    Q = _bf(torch.randn(M, Nj, device=DEV))
+    C0 = torch.zeros(100, Nj, device=DEV)
+    C1 = torch.zeros(90, Nj, device=DEV)
+    rng = torch.tensor([100, 700], device=DEV, dtype=torch.int32)
+    for splits in (1, 2):
+        C0.zero_(); C1.zero_()
+        slab = torch.empty(splits, Ni, Nj, device=DEV) if splits > 1 else None
+        ops.gemm_tn(P, Q, C0, Ni, Nj, M, C1=C1, split_row=128, rows0=100, rows1=90, m_range=rng, splits=splits, slab=slab)
+        ref = P[100:800].float().t() @ Q[100:800].float()
+        assert _rel(C0, ref[:100]) < 1e-5
+        assert _rel(C1, ref[128:218]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, ks, ke, scale):
+    """fp32 reference with the reference's masked_fill(-max) semantics. q:(B,H,Nq,64) k,v:(B,H,Nk,64); ks,ke:(B,Nq)."""
+    B, H, Nq, _ = q.shape
+    Nk = k.shape[2]
+    s = (q @ k.transpose(-1, -2)) * scale
+    j = torch.arange(Nk, device=q.device)[None, None, :]
+    blocked = ~((j >= ks[:, :, None]) & (j < ke[:, :, None].clamp(max=Nk)))
+    s = s.masked_fill(blocked[:, None], -torch.finfo(torch.float32).max)
+    p = s.softmax(-1)
+    return p @ v
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,kind", [(2, 3, 200, 333, "ragged"), (1, 12, 2048, 2048, "blocks"), (2, 2, 30, 30, "pad"),
+                                             (1, 2, 256, 512, "full")])
+def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
+    D = H * 64
+    # packed layouts like the engine's: q rows [B,Nq,H,64], kv rows [B,Nk,2,H,64]
+    qb = _bf(torch.randn(B, Nq, D, device=DEV))
+    kvb = _bf(torch.randn(B, Nk, 2, D, device=DEV))
+    ks = torch.zeros(B, Nq, dtype=torch.int32, device=DEV)
+    ke = torch.full((B, Nq), Nk, dtype=torch.int32, device=DEV)
+    if kind == "ragged":
+        ks = torch.randint(0, Nk // 2, (B, Nq), device=DEV, dtype=torch.int32)
+        ke = ks + torch.randint(0, Nk // 2, (B, Nq), device=DEV, dtype=torch.int32)   # some empty intervals
+        ke[:, 5] = ks[:, 5]                                                          # force an empty one
+    elif kind == "blocks":
+        bounds = [0, 1009, 1024, 2033, 2048]
+        for a, b_ in zip(bounds[:-1], bounds[1:]):
+            ks[:, a:b_] = a
+            ke[:, a:b_] = b_
+    elif kind == "pad":
+        ke[:] = 17
+    scale = 64 ** -0.5
+    q = qb.view(B, Nq, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    k = kvb[:, :, 0].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    v = kvb[:, :, 1].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    ref = _attn_ref(q, k, v, ks.long(), ke.long(), scale)                # (B,H,Nq,64)
+    o = torch.empty(B, Nq, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, Nq, device=DEV)
+    kp, vp = kvb.data_ptr(), kvb.data_ptr() + D * 2
+    ops.attn_fwd(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o.data_ptr(), Nq * D, D, lse, ks, ke,
+                 Nq, 1, B, H, Nq, Nk, scale)
+    got = o.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+
+    do = _bf(torch.randn(B, Nq, D, device=DEV))
+    ref.backward(do.view(B, Nq, H, 64).permute(0, 2, 1, 3).float())
+    dq = torch.zeros(B, Nq, D, device=DEV, dtype=torch.bfloat16)
+    dkv = torch.zeros(B, Nk, 2, D, device=DEV, dtype=torch.bfloat16)
+    delta = torch.empty(B, H, Nq, device=DEV)
+    ops.attn_bwd(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o.data_ptr(), Nq * D, D,
+                 do.data_ptr(), Nq * D, D, lse, delta, dq.data_ptr(), Nq * D, D, dkv.data_ptr(), Nk * 2 * D, 2 * D,
+                 dkv.data_ptr() + D * 2, Nk * 2 * D, 2 * D, ks, ke, Nq, 1, B, H, Nq, Nk, scale)
+    gq = dq.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
+    gk = dkv[:, :, 0].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    gv = dkv[:, :, 1].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    assert _rel(gq, q.grad) < 2e-2, ("dq", _rel(gq, q.grad))
+    assert _rel(gk, k.grad) < 2e-2, ("dk", _rel(gk, k.grad))
+    assert _rel(gv, v.grad) < 2e-2, ("dv", _rel(gv, v.grad))
+
+
+def test_attention_per_sample_interval():
+    B, H, Nq, Nk = 3, 2, 100, 160
+    D = H * 64
+    qb = _bf(torch.randn(B, Nq, D, device=DEV))
+    kvb = _bf(torch.randn(B, Nk, 2, D, device=DEV))
+    nv = torch.tensor([160, 77, 1], dtype=torch.int32, device=DEV)
+    zero = torch.zeros(B, dtype=torch.int32, device=DEV)
+    o = torch.empty(B, Nq, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, Nq, device=DEV)
+    ops.attn_fwd(qb.data_ptr(), Nq * D, D, kvb.data_ptr(), Nk * 2 * D, 2 * D, kvb.data_ptr() + 2 * D, Nk * 2 * D, 2 * D,
+                 o.data_ptr(), Nq * D, D, lse, zero, nv, 1, 0, B, H, Nq, Nk, 0.125)
+    q = qb.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
+    k = kvb[:, :, 0].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    v = kvb[:, :, 1].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    ref = _attn_ref(q, k, v, zero[:, None].expand(B, Nq).long(), nv[:, None].expand(B, Nq).long(), 0.125)
+    assert _rel(o.view(B, Nq, H, 64).permute(0, 2, 1, 3).float(), ref) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize("rows,D", [(1000, 768), (37, 128), (513, 1152)])
+def test_layernorm(rows, D):
+    x = torch.randn(rows, D, device=DEV) * 2 + 0.3
+    w = torch.randn(D, device=DEV) * 0.1 + 1
+    perm = torch.randperm(rows, device=DEV).int()
+    perm[3] = -1
+    y = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, w, y, mean, rstd, out_row=perm)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, None, 1e-6)
+    keep = perm >= 0
+    assert _rel(y[perm[keep].long()].float(), ref[keep]) < 4e-3
+    dy = _bf(torch.randn(rows, D, device=DEV))           # stored in the permuted row order
+    dy_rows = torch.zeros(rows, D, device=DEV)
+    dy_rows[keep] = dy[perm[keep].long()].float()
+    ref.backward(dy_rows)
+    dx_in = torch.randn(rows, D, device=DEV)
+    dx = torch.empty(rows, D, device=DEV)
+    dxb = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    dw = torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, dx_in=dx_in, dx_bf16=dxb, dy_row=perm)
+    assert _rel(dx, dx_in + xr.grad) < 1e-5
+    assert _rel(dxb.float(), dx_in + xr.grad) < 4e-3
+    assert _rel(dw, wr.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ swiglu / casts / CE
+def test_swiglu():
+    rows, F = 777, 2048
+    ab = _bf(torch.randn(rows, 2 * F, device=DEV))
+    h = torch.empty(rows, F, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_fwd(ab, h, rows, F)
+    a = ab[:, :F].float().requires_grad_(True)
+    b = ab[:, F:].float().requires_grad_(True)
+    ref = torch.nn.functional.silu(a) * b
+    assert _rel(h.float(), ref) < 6e-3
+    dh = _bf(torch.randn(rows, F, device=DEV))
+    ref.backward(dh.float())
+    dab = torch.empty(rows, 2 * F, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_bwd(ab, dh, dab, rows, F)
+    assert _rel(dab[:, :F].float(), a.grad) < 4e-3
+    assert _rel(dab[:, F:].float(), b.grad) < 4e-3
+
+
+def test_cast_weight_pad_and_transpose():
+    W = torch.randn(341, 128, device=DEV)
+    Wb = torch.full((384, 128), 9.0, device=DEV, dtype=torch.bfloat16)
+    Wt = torch.full((128, 384), 9.0, device=DEV, dtype=torch.bfloat16)
+    ops.cast_weight(W, Wb, Wt, rows_dst=384)
+    assert torch.equal(Wb[:341], _bf(W)) and (Wb[341:] == 0).all()
+    assert torch.equal(Wt[:, :341], _bf(W).t()) and (Wt[:, 341:] == 0).all()
+
+
+def test_cross_entropy():
+    n_total, V = 300, 64000
+    logits = _bf(torch.randn(n_total, V, device=DEV) * 2)
+    tgt = torch.randint(0, V, (n_total,), device=DEV, dtype=torch.int32)
+    rng = torch.tensor([40, 200], device=DEV, dtype=torch.int32)
+    lse = torch.zeros(n_total, device=DEV)
+    nll = torch.zeros(n_total, device=DEV)
+    ops.ce_fwd(logits, V, V, tgt, rng, 260, lse, nll)
+    lf = logits[40:240].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, tgt[40:240].long(), reduction="none")
+    assert _rel(nll[40:240], ref) < 1e-5
+    out = torch.zeros(3, device=DEV)
+    ranges = torch.tensor([40, 200, 0, 0], device=DEV, dtype=torch.int32)
+    ops.loss_finalize(nll, ranges, 2, out)
+    assert abs(out[1].item() - ref.mean().item()) < 1e-4 and out[2].item() == 0
+    assert abs(out[0].item() - ref.mean().item() / 2) < 1e-4
+    (ref.mean() / 2 * 0.5).backward()
+    g = torch.tensor([0.5], device=DEV)
+    keep = logits.clone()
+    ops.ce_bwd(logits, V, V, tgt, rng, 260, lse, g, 2)
+    assert _rel(logits[40:240].float(), lf.grad) < 5e-3
+    assert torch.equal(logits[:40], keep[:40]) and torch.equal(logits[240:], keep[240:])
+
+
+def test_bias_grad_and_cast():
+    g = _bf(torch.randn(1000, 768, device=DEV))
+    db = torch.zeros(768, device=DEV)
+    ops.bias_grad(g, 1000, 768, db)
+    assert _rel(db, g.float().sum(0)) < 1e-5
+    src = torch.randn(4096, device=DEV)
+    dst = torch.empty(4096, device=DEV, dtype=torch.bfloat16)
+    ops.cast_f32_bf16(src, dst)
+    assert torch.equal(dst, _bf(src))
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def test_adamw_matches_torch():
+    n = 100003
+    p0 = torch.randn(n + 1, device=DEV)[:n]          # keep 16-byte alignment of the base
+    p0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p = p0.clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    sq = torch.zeros(1, device=DEV, dtype=torch.float64)
+    for step in (1, 2, 3):
+        gs = g * step
+        pr.grad = gs.clone()
+        total = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        sq.zero_()
+        graw = gs.clone()
+        ops.grad_sqnorm(graw, sq)
+        assert abs(math.sqrt(sq.item()) - total.item()) < 1e-4 * total.item()
+        ops.adamw_step(p, graw, m, v, 1e-3, 0.05, step, gscale=1.0, max_norm=1.0, sqnorm=sq, zero_grad=True)
+        assert (graw == 0).all()
+        assert _rel(p, pr.detach()) < 1e-6
