@@ -498,7 +498,7 @@ extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -523,13 +523,13 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     {
         const long waves = (long)B * Nq;
         const int blocks = (int)((waves * 64 + 255) / 256);
-        hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)O, o_bs, o_rs,
+        EGO_LAUNCH(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)O, o_bs, o_rs,
                            (const bf16_t*)dO, do_bs, do_rs, DELTA, B, H, Nq);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -17,6 +17,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define EGO_ERR_ARG 1
 #define EGO_ERR_LAUNCH 2
 
+// clear any stale (non-sticky) error left by an earlier, unrelated HIP call, then launch
+#define EGO_LAUNCH(...)                  \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define LAUNCH_CHECK()                                        \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

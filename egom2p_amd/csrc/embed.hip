@@ -284,7 +284,7 @@ extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream)
     a.ids_keep = (long long*)d->ids_keep; a.pad = (unsigned char*)d->pad; a.mod_mask = (short*)d->mod_mask;
     a.slot = d->slot; a.local = d->local; a.tok = d->tok; a.ks = d->ks; a.ke = d->ke;
     a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err;
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(compact_kernel, dim3(B), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -295,7 +295,7 @@ extern "C" int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream) {
     for (int m = 0; m < EGO_MAX_MODS; ++m) { a.table[m] = d->table[m]; a.pos[m] = d->pos[m]; a.mod[m] = d->mod[m]; }
     a.base_vec = d->base_vec; a.slot = d->slot; a.local = d->local; a.tok = d->tok;
     a.x = d->x; a.emb = d->emb; a.rows = d->rows; a.D = d->D;
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, stream, a);
+    EGO_LAUNCH(embed_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -303,7 +303,7 @@ extern "C" int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream) {
 extern "C" int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* tok, int B, int M,
                              int n_mods, int* perm, int* tgt_perm, int* ranges, int* base, hipStream_t stream) {
     if (B <= 0 || M <= 0 || n_mods <= 0 || n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(loss_perm_kernel, dim3(1), dim3(256), 0, stream, seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base);
+    EGO_LAUNCH(loss_perm_kernel, dim3(1), dim3(256), 0, stream, seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -316,7 +316,7 @@ extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
     a.rows = d->rows; a.D = d->D; a.n_mods = d->n_mods;
     const size_t lds = (size_t)(d->n_mods + 1) * d->D * sizeof(float);
     if (lds > 64 * 1024) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((d->rows + 63) / 64)), dim3(256), lds, stream, a);
+    EGO_LAUNCH(embed_bwd_kernel, dim3((unsigned)((d->rows + 63) / 64)), dim3(256), lds, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

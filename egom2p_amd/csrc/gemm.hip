@@ -313,7 +313,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     ensure_attrs();
     NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS, stream, a);
+    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -328,12 +328,12 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
     const int tiles = (Ni / BM) * (Nj / BN);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), GEMM_LDS, stream, a);
+    EGO_LAUNCH(gemm_tn_kernel, dim3(tiles * splits), dim3(256), GEMM_LDS, stream, a);
     LAUNCH_CHECK();
     if (splits > 1) {
         const long total = (long)Ni * (Nj / 4);
         const int blocks = (int)min((long)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, C0, C1, ldc, split_row, rows0, rows1, Ni, Nj, splits);
+        EGO_LAUNCH(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, C0, C1, ldc, split_row, rows0, rows1, Ni, Nj, splits);
         LAUNCH_CHECK();
     }
     return EGO_OK;

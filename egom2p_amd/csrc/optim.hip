@@ -82,7 +82,7 @@ extern "C" int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t 
     if (((uintptr_t)g) % 16) return EGO_ERR_ARG;
     const long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, g, n4, n, out);
+    EGO_LAUNCH(sqnorm_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, g, n4, n, out);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -96,7 +96,7 @@ extern "C" int ego_adamw_step(float* p, float* g, float* m, float* v, long n, fl
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     const long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, p, g, m, v, n, lr, wd, beta1, beta2, eps,
+    EGO_LAUNCH(adamw_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, p, g, m, v, n, lr, wd, beta1, beta2, eps,
                        bc1, bc2s, gscale, max_norm, sqnorm, zero_grad);
     LAUNCH_CHECK();
     return EGO_OK;
@@ -105,7 +105,7 @@ extern "C" int ego_adamw_step(float* p, float* g, float* m, float* v, long n, fl
 extern "C" int ego_grad_scale(float* g, long n, float gscale, float max_norm, const double* sqnorm, hipStream_t stream) {
     if (n <= 0) return EGO_OK;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, stream, g, n, gscale, max_norm, sqnorm);
+    EGO_LAUNCH(scale_kernel, dim3(blocks), dim3(256), 0, stream, g, n, gscale, max_norm, sqnorm);
     LAUNCH_CHECK();
     return EGO_OK;
 }

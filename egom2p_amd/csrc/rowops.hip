@@ -336,7 +336,7 @@ extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float*
                                  const int* out_row, int rows, int D, float eps, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
     if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
-#define LN_FWD(C) hipLaunchKernelGGL(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps)
+#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps)
     if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else if (D <= 1536) LN_FWD(6); else LN_FWD(8);
 #undef LN_FWD
     LAUNCH_CHECK();
@@ -348,7 +348,7 @@ extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float*
                                  void* dx_bf16, float* dw, int rows, int D, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
     if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
-#define LN_BWD(C) hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, stream, (const bf16_t*)dy, \
+#define LN_BWD(C) EGO_LAUNCH(ln_bwd_kernel<C>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, stream, (const bf16_t*)dy, \
                        dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, dw, rows, D)
     if (D <= 768) LN_BWD(3); else if (D <= 1024) LN_BWD(4); else if (D <= 1536) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD
@@ -359,7 +359,7 @@ extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float*
 extern "C" int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
     if (F % 8) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (bf16_t*)h, rows, F);
+    EGO_LAUNCH(swiglu_fwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (bf16_t*)h, rows, F);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -367,7 +367,7 @@ extern "C" int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStre
 extern "C" int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long rows, int F, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
     if (F % 8) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (const bf16_t*)dh, (bf16_t*)dab, rows, F);
+    EGO_LAUNCH(swiglu_bwd_kernel, dim3(grid_for(rows * (F / 8))), dim3(256), 0, stream, (const bf16_t*)ab, (const bf16_t*)dh, (bf16_t*)dab, rows, F);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -375,7 +375,7 @@ extern "C" int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long ro
 extern "C" int ego_cast_weight(const float* W, int rows, int cols, long ld_src, void* Wb, long ld_w, void* Wt, long ld_t,
                                int rows_dst, hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || rows_dst < rows) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(cast_w_kernel, dim3((cols + 31) / 32, (rows_dst + 31) / 32), dim3(256), 0, stream, W, rows, cols, ld_src,
+    EGO_LAUNCH(cast_w_kernel, dim3((cols + 31) / 32, (rows_dst + 31) / 32), dim3(256), 0, stream, W, rows, cols, ld_src,
                        (bf16_t*)Wb, ld_w, (bf16_t*)Wt, ld_t, rows_dst);
     LAUNCH_CHECK();
     return EGO_OK;
@@ -384,7 +384,7 @@ extern "C" int ego_cast_weight(const float* W, int rows, int cols, long ld_src, 
 extern "C" int ego_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
     if (n <= 0) return EGO_OK;
     if (n % 4) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, src, (bf16_t*)dst, n / 4);
+    EGO_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, src, (bf16_t*)dst, n / 4);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -393,7 +393,7 @@ extern "C" int ego_ce_fwd(const void* logits, long ld, int V, const int* targets
                           float* lse, float* nll, hipStream_t stream) {
     if (max_rows <= 0) return EGO_OK;
     if (V % 8 || ld % 8) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(max_rows), dim3(256), 0, stream, (const bf16_t*)logits, ld, V, targets, range, lse, nll);
+    EGO_LAUNCH(ce_fwd_kernel, dim3(max_rows), dim3(256), 0, stream, (const bf16_t*)logits, ld, V, targets, range, lse, nll);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -402,21 +402,21 @@ extern "C" int ego_ce_bwd(void* logits, long ld, int V, const int* targets, cons
                           const float* lse, const float* gscale, int n_mods, hipStream_t stream) {
     if (max_rows <= 0) return EGO_OK;
     if (V % 8 || ld % 8 || n_mods <= 0) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods);
+    EGO_LAUNCH(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods);
     LAUNCH_CHECK();
     return EGO_OK;
 }
 
 extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream) {
     if (n_mods <= 0) return EGO_ERR_ARG;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, nll, ranges, n_mods, out);
+    EGO_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, nll, ranges, n_mods, out);
     LAUNCH_CHECK();
     return EGO_OK;
 }
 
 extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((D + 255) / 256, (int)((rows + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)g, rows, D, db);
+    EGO_LAUNCH(bias_grad_kernel, dim3((D + 255) / 256, (int)((rows + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)g, rows, D, db);
     LAUNCH_CHECK();
     return EGO_OK;
 }

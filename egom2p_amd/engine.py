@@ -1,0 +1,555 @@
+"""EgoM2P training/inference engine for one MI355X: owns the flat fp32 parameter / gradient buffers,
+the bf16 weight copies, the activation workspaces, and issues the HIP kernels of one forward and one
+hand-ordered backward pass (no autograd graph, no tracing compiler).
+
+Dataflow = `EgoM2P.forward` of the reference (egom2p/models/egom2p_model.py:683-734) with the
+autocast(bf16) numerics of `run_training_egom2p.py:725`: GEMM-class ops in bf16 with fp32 MFMA
+accumulation, LayerNorm / softmax / cross-entropy / residual stream in fp32.
+
+Layout decisions (MI355X-first, 288 GB HBM):
+  * every parameter lives in ONE flat fp32 buffer in forward order; gradients in a twin buffer, so
+    gradients become final from the tail backwards and per-layer slices are the all-reduce buckets;
+  * every activation needed by the backward is kept (1.7 GB per clip at ego-b): no recompute;
+  * decoder rows are written modality-grouped by the final LayerNorm so the per-modality logits / CE
+    run on contiguous row ranges whose (offset, count) stay on the device (no host sync anywhere);
+  * MLP hidden size is padded to a multiple of 128 in the masters themselves (pad entries are exactly
+    zero and stay zero), so every GEMM dimension is tile-aligned.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .config import ModelCfg, Modality
+from .posemb import build_pos_emb
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+I32 = torch.int32
+
+
+def _pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+class _Lin:
+    """One linear layer: master view [out, in] (possibly padded), bf16 W [out, in] and W^T [in, out]."""
+    __slots__ = ("name", "w", "g", "wb", "wt", "out_f", "in_f")
+
+    def __init__(self, name, w, g, dev):
+        self.name, self.w, self.g = name, w, g
+        self.out_f, self.in_f = w.shape
+        self.wb = torch.zeros(self.out_f, self.in_f, device=dev, dtype=BF16)
+        self.wt = torch.zeros(self.in_f, self.out_f, device=dev, dtype=BF16)
+
+
+class Engine:
+    def __init__(self, cfg: ModelCfg, device="cuda:0", max_batch: int = 1, n_enc: int = 2048, n_dec: int = 2048):
+        L.load()  # fail loudly if the HIP library is missing
+        if cfg.dim % 128 or cfg.head_dim != 64:
+            raise L.EgoHipError(f"engine needs dim % 128 == 0 and head_dim == 64 (got dim={cfg.dim}, head_dim={cfg.head_dim})")
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.D, self.H = cfg.dim, cfg.num_heads
+        self.F, self.Fp = cfg.mlp_hidden, _pad128(cfg.mlp_hidden)
+        self.mods: List[Modality] = cfg.mods
+        self.n_mods = len(self.mods)
+        self.N, self.M, self.Bmax = n_enc, n_dec, max_batch
+        self.scale = cfg.head_dim ** -0.5
+        self._build_params()
+        self._alloc_workspaces()
+        self.weights_dirty = True
+        self._have_fwd = False
+
+    # ------------------------------------------------------------------------------------ parameters
+    def _build_params(self):
+        D, Fp, cfg = self.D, self.Fp, self.cfg
+        spec: List[Tuple[str, Tuple[int, ...]]] = []
+        groups: List[Tuple[str, int, int]] = []      # (group name, lo, hi) = all-reduce buckets, forward order
+
+        def add(name, shape):
+            spec.append((name, tuple(shape)))
+
+        def layer(prefix, kind):
+            norms = ["norm1", "norm2"] if kind == "enc" else ["norm1", "query_norm", "context_norm", "norm2"]
+            for n in norms:
+                add(f"{prefix}.{n}.weight", (D,))
+            if kind == "enc":
+                add(f"{prefix}.attn.qkv.weight", (3 * D, D))
+                add(f"{prefix}.attn.proj.weight", (D, D))
+            else:
+                add(f"{prefix}.self_attn.qkv.weight", (3 * D, D))
+                add(f"{prefix}.self_attn.proj.weight", (D, D))
+                add(f"{prefix}.cross_attn.q.weight", (D, D))
+                add(f"{prefix}.cross_attn.kv.weight", (2 * D, D))
+                add(f"{prefix}.cross_attn.proj.weight", (D, D))
+            add(f"{prefix}.mlp.fc1.weight", (Fp, D))      # fc1 | fc3 adjacent: one fused [2Fp, D] GEMM operand
+            add(f"{prefix}.mlp.fc3.weight", (Fp, D))
+            add(f"{prefix}.mlp.fc2.weight", (D, Fp))
+
+        marks = []
+        for m in self.mods:
+            marks.append((f"enc_table.{m.name}", len(spec)))
+            add(f"encoder_embeddings.{m.name}.token_emb.weight", (m.vocab_size, D))
+        marks.append(("mod_emb", len(spec)))
+        for m in self.mods:
+            add(f"encoder_embeddings.{m.name}.mod_emb", (D,))
+        for i in range(cfg.encoder_depth):
+            marks.append((f"encoder.{i}", len(spec)))
+            layer(f"encoder.{i}", "enc")
+        marks.append(("bridge", len(spec)))
+        add("encoder_norm.weight", (D,))
+        add("decoder_proj_context.bias", (D,))
+        add("decoder_proj_context.weight", (D, D))
+        for i in range(cfg.decoder_depth):
+            marks.append((f"decoder.{i}", len(spec)))
+            layer(f"decoder.{i}", "dec")
+        marks.append(("head", len(spec)))
+        add("decoder_norm.weight", (D,))
+        add("mask_token", (D,))
+        for m in self.mods:
+            marks.append((f"dec_table.{m.name}", len(spec)))
+            add(f"decoder_embeddings.{m.name}.token_emb.weight", (m.vocab_size, D))
+        if not cfg.share_embedding:
+            for m in self.mods:
+                marks.append((f"to_logits.{m.name}", len(spec)))
+                add(f"decoder_embeddings.{m.name}.to_logits.weight", (m.vocab_size, D))
+
+        offs, total = {}, 0
+        for name, shape in spec:
+            n = math.prod(shape)
+            offs[name] = (total, n, shape)
+            total += (n + 3) // 4 * 4
+        self.n_flat = total
+        self.P = torch.zeros(total, device=self.dev, dtype=F32)
+        self.G = torch.zeros(total, device=self.dev, dtype=F32)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        self.offsets = offs
+        for name, (o, n, shape) in offs.items():
+            self.p[name] = self.P[o:o + n].view(shape)
+            self.g[name] = self.G[o:o + n].view(shape)
+        starts = [offs[spec[i][0]][0] for _, i in marks] + [total]
+        self.buckets = [(marks[i][0], starts[i], starts[i + 1]) for i in range(len(marks))]
+        # optimiser runs: contiguous ranges of equal weight-decay class (no_decay: norm weights and biases)
+        runs: List[List] = []
+        for name, shape in spec:
+            o, n, _ = offs[name]
+            nd = ("norm." in name or ".norm" in name or name.endswith(".bias"))
+            n4 = (n + 3) // 4 * 4
+            if runs and runs[-1][2] == nd and runs[-1][1] == o:
+                runs[-1][1] = o + n4
+            else:
+                runs.append([o, o + n4, nd])
+        self.opt_runs = [(a, b, nd) for a, b, nd in runs]
+        # fixed positional tables (buffers)
+        self.pos = {m.name: build_pos_emb(m, D)[0].to(self.dev).contiguous() for m in self.mods}
+
+        # linear layers: bf16 copies
+        self.lin: Dict[str, _Lin] = {}
+
+        def lin(name):
+            self.lin[name] = _Lin(name, self.p[name], self.g[name], self.dev)
+
+        for i in range(cfg.encoder_depth):
+            for s in ("attn.qkv", "attn.proj", "mlp.fc2"):
+                lin(f"encoder.{i}.{s}.weight")
+            self._fuse13(f"encoder.{i}")
+        for i in range(cfg.decoder_depth):
+            for s in ("self_attn.qkv", "self_attn.proj", "cross_attn.q", "cross_attn.kv", "cross_attn.proj", "mlp.fc2"):
+                lin(f"decoder.{i}.{s}.weight")
+            self._fuse13(f"decoder.{i}")
+        lin("decoder_proj_context.weight")
+        for m in self.mods:
+            key = (f"decoder_embeddings.{m.name}.token_emb.weight" if cfg.share_embedding
+                   else f"decoder_embeddings.{m.name}.to_logits.weight")
+            lin(key)
+        self.logit_key = {m.name: (f"decoder_embeddings.{m.name}.token_emb.weight" if cfg.share_embedding
+                                   else f"decoder_embeddings.{m.name}.to_logits.weight") for m in self.mods}
+
+    def _fuse13(self, prefix):
+        """fc1 and fc3 are adjacent in the flat buffer: expose them as one [2Fp, D] linear."""
+        o1 = self.offsets[f"{prefix}.mlp.fc1.weight"][0]
+        n = 2 * self.Fp * self.D
+        w = self.P[o1:o1 + n].view(2 * self.Fp, self.D)
+        g = self.G[o1:o1 + n].view(2 * self.Fp, self.D)
+        self.lin[f"{prefix}.mlp.fc13"] = _Lin(f"{prefix}.mlp.fc13", w, g, self.dev)
+
+    # reference key layout <-> engine storage ----------------------------------------------------
+    def _view_for_key(self, key: str) -> Optional[torch.Tensor]:
+        F, Fp = self.F, self.Fp
+        if key.endswith("pos_emb") or (key.endswith(".bias") and "norm" in key):
+            return None                                   # buffers: pos tables are rebuilt, LN bias is a zero buffer
+        k = key.replace("decoder_embeddings", "DE").replace("encoder_embeddings", "EE")
+        if k.startswith("DE") and k.endswith("mod_emb"):
+            key = key.replace("decoder_embeddings", "encoder_embeddings")      # shared Parameter
+        if key.endswith("to_logits.weight") and self.cfg.share_embedding:
+            key = key.replace("to_logits.weight", "token_emb.weight")          # tied
+        t = self.p[key]
+        if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
+            return t[:F]
+        if key.endswith("mlp.fc2.weight"):
+            return t[:, :F]
+        return t
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for key, val in sd.items():
+            v = self._view_for_key(key)
+            if v is None:
+                continue
+            v.copy_(val.to(self.dev, F32).reshape(v.shape))
+        self.weights_dirty = True
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        cfg, D = self.cfg, self.D
+        for m in self.mods:
+            e, d = f"encoder_embeddings.{m.name}", f"decoder_embeddings.{m.name}"
+            out[f"{e}.mod_emb"] = self.p[f"{e}.mod_emb"].view(1, 1, D)
+            out[f"{e}.token_emb.weight"] = self.p[f"{e}.token_emb.weight"]
+            out[f"{e}.pos_emb"] = self.pos[m.name][None]
+            out[f"{d}.mod_emb"] = out[f"{e}.mod_emb"]
+            out[f"{d}.token_emb.weight"] = self.p[f"{d}.token_emb.weight"]
+            out[f"{d}.to_logits.weight"] = self.p[self.logit_key[m.name]]
+            out[f"{d}.pos_emb"] = self.pos[m.name][None]
+        zeros = torch.zeros(D, device=self.dev)
+        for name in self.p:
+            if name.startswith(("encoder.", "decoder.", "encoder_norm", "decoder_norm", "decoder_proj_context")):
+                out[name] = self._view_for_key(name)
+                if name.endswith("norm.weight") or ".norm" in name or "norm1" in name or "norm2" in name:
+                    out[name[:-len("weight")] + "bias"] = zeros
+        out["mask_token"] = self.p["mask_token"].view(1, 1, D)
+        return out
+
+    def grad_of(self, key: str) -> torch.Tensor:
+        F = self.F
+        if key.startswith("decoder_embeddings") and key.endswith("mod_emb"):
+            key = key.replace("decoder_embeddings", "encoder_embeddings")
+        if key.endswith("to_logits.weight") and self.cfg.share_embedding:
+            key = key.replace("to_logits.weight", "token_emb.weight")
+        t = self.g[key]
+        if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
+            return t[:F]
+        if key.endswith("mlp.fc2.weight"):
+            return t[:, :F]
+        return t
+
+    def param_names(self) -> List[str]:
+        return list(self.p.keys())
+
+    def num_params(self) -> int:
+        n = 0
+        for name, t in self.p.items():
+            v = self._view_for_key(name)
+            n += v.numel()
+        return n
+
+    def refresh_weights(self):
+        """fp32 masters -> bf16 W and W^T copies (once per optimiser step; autocast re-casts per forward)."""
+        for name, l in self.lin.items():
+            ops.cast_weight(l.w, l.wb, l.wt)
+        self.weights_dirty = False
+
+    # ------------------------------------------------------------------------------------ workspaces
+    def _alloc_workspaces(self):
+        B, N, M, D, Fp, H = self.Bmax, self.N, self.M, self.D, self.Fp, self.H
+        dev, cfg = self.dev, self.cfg
+        RN, RM = B * N, B * M
+
+        def e(*shape, dt=BF16):
+            return torch.empty(*shape, device=dev, dtype=dt)
+
+        def side(n_keep, n_rows):
+            return dict(ids_keep=e(B, n_keep, dt=torch.int64), pad=e(B, n_keep, dt=torch.uint8),
+                        mod_mask=e(B, n_keep, dt=torch.int16), slot=e(B, n_keep, dt=I32), local=e(B, n_keep, dt=I32),
+                        tok=e(B, n_keep, dt=I32), ks=e(B, n_keep, dt=I32), ke=e(B, n_keep, dt=I32),
+                        n_valid=e(B, dt=I32), seg=e(B, self.n_mods, 2, dt=I32), err=torch.zeros(1, device=dev, dtype=I32))
+
+        self.ce, self.cd = side(N, RN), side(M, RM)
+        self.zero_b = torch.zeros(B, device=dev, dtype=I32)
+        self.emb_e = e(RN, D, dt=F32)
+        self.perm = e(RM, dt=I32)
+        self.tgt_perm = torch.zeros(RM, device=dev, dtype=I32)
+        self.ranges = torch.zeros(self.n_mods, 2, device=dev, dtype=I32)
+        self.perm_base = e(B, self.n_mods, dt=I32)
+        self.canon = e(self.n_mods, dt=I32)
+
+        def enc_layer():
+            return dict(x=e(RN, D, dt=F32), xm=e(RN, D, dt=F32), ln1=e(RN, D), qkv=e(RN, 3 * D), ao=e(RN, D),
+                        lse=e(B, H, N, dt=F32), st1=e(2, RN, dt=F32), ln2=e(RN, D), ab=e(RN, 2 * Fp), h=e(RN, Fp),
+                        st2=e(2, RN, dt=F32))
+
+        def dec_layer():
+            return dict(x=e(RM, D, dt=F32), x1=e(RM, D, dt=F32), x2=e(RM, D, dt=F32), ln1=e(RM, D), qkv=e(RM, 3 * D),
+                        ao=e(RM, D), lse=e(B, H, M, dt=F32), st1=e(2, RM, dt=F32), qn=e(RM, D), q=e(RM, D),
+                        stq=e(2, RM, dt=F32), cn=e(RN, D), kv=e(RN, 2 * D), stc=e(2, RN, dt=F32), xo=e(RM, D),
+                        lse_x=e(B, H, M, dt=F32), ln2=e(RM, D), ab=e(RM, 2 * Fp), h=e(RM, Fp), st2=e(2, RM, dt=F32))
+
+        self.enc = [enc_layer() for _ in range(cfg.encoder_depth)]
+        self.dec = [dec_layer() for _ in range(cfg.decoder_depth)]
+        self.x_enc_out = e(RN, D, dt=F32)          # residual stream after the last encoder block
+        self.st_en = e(2, RN, dt=F32)
+        self.xe = e(RN, D)                         # encoder_norm output (bf16)
+        self.ctx = e(RN, D, dt=F32)
+        self.y_out = e(RM, D, dt=F32)
+        self.st_dn = e(2, RM, dt=F32)
+        self.yn = torch.zeros(RM, D, device=dev, dtype=BF16)     # decoder_norm output, modality-grouped rows
+        vs = sorted({m.vocab_size for m in self.mods})
+        self.logits = {v: e(RM, v) for v in vs}
+        self.lse_ce = e(RM, dt=F32)
+        self.nll = torch.zeros(RM, device=dev, dtype=F32)
+        self.loss_out = torch.zeros(1 + self.n_mods, device=dev, dtype=F32)
+        # backward temporaries
+        R = max(RN, RM)
+        self.dres = e(RM, D, dt=F32)               # decoder residual-stream gradient
+        self.dres_b = e(RM, D)
+        self.dctx = e(RN, D, dt=F32)
+        self.dctx_b = e(RN, D)
+        self.dxe = e(RN, D, dt=F32)                # encoder residual-stream gradient
+        self.dxe_b = e(RN, D)
+        self.t_d = e(R, D)                         # generic [rows, D] bf16 temp
+        self.t_d2 = e(R, D)
+        self.t_3d = e(R, 3 * D)
+        self.t_2d = e(RN, 2 * D)
+        self.t_f = e(R, Fp)
+        self.t_2f = e(R, 2 * Fp)
+        self.dyn = torch.zeros(RM, D, device=dev, dtype=BF16)
+        self.delta = e(B, H, max(N, M), dt=F32)
+        self.slab = e(48 * 1024 * 1024 // 4 * 1, dt=F32) if True else None   # 48 MiB of split-K partials
+        self.gscale = torch.ones(1, device=dev, dtype=F32)
+
+    # ------------------------------------------------------------------------------------ small helpers
+    def _lin_fwd(self, name, A, C, rows, epi=L.EPI_BF16, R=None, bias=None):
+        l = self.lin[name]
+        ops.gemm_nt(A, l.wb, C, rows, l.out_f, l.in_f, epi, R=R, bias=bias, lda=A.shape[-1], ldb=l.in_f, ldc=C.shape[-1],
+                    ldr=None if R is None else R.shape[-1])
+
+    def _lin_bwd(self, name, dY, X, dX, rows):
+        """dX(bf16) = dY @ W ; dW += dY^T @ X."""
+        l = self.lin[name]
+        if dX is not None:
+            ops.gemm_nt(dY, l.wt, dX, rows, l.in_f, l.out_f, L.EPI_BF16, lda=dY.shape[-1], ldb=l.out_f, ldc=dX.shape[-1])
+        tiles = (l.out_f // 128) * (l.in_f // 128)
+        steps = max(1, (rows + 63) // 64)
+        splits = max(1, min(steps, (512 + tiles - 1) // tiles, self.slab.numel() // (l.out_f * l.in_f)))
+        ops.gemm_tn(dY, X, l.g, l.out_f, l.in_f, rows, splits=splits, slab=self.slab if splits > 1 else None,
+                    ldp=dY.shape[-1], ldq=X.shape[-1], ldc=l.in_f)
+
+    def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk):
+        D = self.D
+        ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
+                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, lse, ks, ke, r_bs, r_rs,
+                     B, self.H, Nq, Nk, self.scale)
+
+    def _attn_bwd(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, do_t, lse, dq_t, dkv_t, ks, ke, r_bs, r_rs, B, Nq, Nk):
+        D = self.D
+        ops.attn_bwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
+                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, do_t.data_ptr(), Nq * D, D,
+                     lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
+                     kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale)
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
+                need_loss: bool = True):
+        """Forward of one micro-batch (tensors already on the device).  Returns (loss, {mod: loss}) as
+        views of a device buffer: reading them is the only host sync."""
+        if self.weights_dirty:
+            self.refresh_weights()
+        cfg, D, Fp, N, M = self.cfg, self.D, self.Fp, self.N, self.M
+        mods = self.mods
+        B = mod_dict[mods[0].name]["input_mask"].shape[0]
+        if B > self.Bmax:
+            raise L.EgoHipError(f"batch {B} exceeds the engine's workspace batch {self.Bmax}")
+        self.B = B
+        RN, RM = B * N, B * M
+        byname = {m.name: m for m in mods}
+        dmods = [byname[n] for n in (dec_order or [m.name for m in mods])]
+        self.dmods = dmods
+
+        def flat_ids(m):
+            t = mod_dict[m.name]["tensor"]
+            return t.reshape(B, -1).contiguous()
+
+        # ---- compaction + embeddings (egom2p_model.py:706-718, 723)
+        ce, cd = self.ce, self.cd
+        ops.compact([mod_dict[m.name]["input_mask"] for m in mods], [flat_ids(m) for m in mods], None,
+                    [m.max_tokens for m in mods], [m.id for m in mods], N, False, ce, B)
+        ops.compact([mod_dict[m.name]["target_mask"] for m in dmods], [flat_ids(m) for m in dmods],
+                    [mod_dict[m.name]["decoder_attention_mask"] for m in dmods],
+                    [m.max_tokens for m in dmods], [m.id for m in dmods], M, True, cd, B)
+        x0 = self.enc[0]["x"] if cfg.encoder_depth else self.x_enc_out
+        ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
+                      [self.pos[m.name] for m in mods], [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods],
+                      None, ce["slot"], ce["local"], ce["tok"], x0, self.emb_e, RN, D)
+        y0 = self.dec[0]["x"] if cfg.decoder_depth else self.y_out
+        ops.embed_fwd(None, [self.pos[m.name] for m in dmods], [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods],
+                      self.p["mask_token"], cd["slot"], cd["local"], cd["tok"], y0, None, RM, D)
+        self.canon.copy_(torch.tensor([mods.index(m) for m in dmods], dtype=I32), non_blocking=True)
+        ops.loss_perm(cd["seg"], self.canon, cd["slot"], cd["tok"], B, M, self.n_mods, self.perm, self.tgt_perm,
+                      self.ranges, self.perm_base)
+
+        # ---- encoder (egom2p_model.py:496-499; Block.forward egom2p_utils.py:356-359)
+        for i, w in enumerate(self.enc):
+            pre = f"encoder.{i}"
+            nxt = self.enc[i + 1]["x"] if i + 1 < cfg.encoder_depth else self.x_enc_out
+            ops.layernorm_fwd(w["x"][:RN], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln1"], w["qkv"], RN)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], ce["ks"], ce["ke"], N, 1, B, N, N)
+            self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
+            ops.layernorm_fwd(w["xm"][:RN], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.mlp.fc13", w["ln2"], w["ab"], RN)
+            ops.swiglu_fwd(w["ab"], w["h"], RN, Fp)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RN, L.EPI_RESID, R=w["xm"])
+        ops.layernorm_fwd(self.x_enc_out[:RN], self.p["encoder_norm.weight"], self.xe, self.st_en[0], self.st_en[1], eps=cfg.eps)
+        # context = decoder_proj_context(x) + encoder_emb   (egom2p_model.py:722)
+        self._lin_fwd("decoder_proj_context.weight", self.xe, self.ctx, RN, L.EPI_BIAS_RESID, R=self.emb_e,
+                      bias=self.p["decoder_proj_context.bias"])
+
+        # ---- decoder (egom2p_model.py:520-523; DecoderBlock.forward egom2p_utils.py:387-391)
+        for i, w in enumerate(self.dec):
+            pre = f"decoder.{i}"
+            nxt = self.dec[i + 1]["x"] if i + 1 < cfg.decoder_depth else self.y_out
+            ops.layernorm_fwd(w["x"][:RM], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln1"], w["qkv"], RM)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M)
+            self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
+            ops.layernorm_fwd(w["x1"][:RM], self.p[f"{pre}.query_norm.weight"], w["qn"], w["stq"][0], w["stq"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
+            ops.layernorm_fwd(self.ctx[:RN], self.p[f"{pre}.context_norm.weight"], w["cn"], w["stc"][0], w["stc"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
+            self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N)
+            self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["xo"], w["x2"], RM, L.EPI_RESID, R=w["x1"])
+            ops.layernorm_fwd(w["x2"][:RM], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.mlp.fc13", w["ln2"], w["ab"], RM)
+            ops.swiglu_fwd(w["ab"], w["h"], RM, Fp)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RM, L.EPI_RESID, R=w["x2"])
+        # decoder_norm, rows written modality-grouped (the row order of y[decoder_mod_mask == id], :633)
+        ops.layernorm_fwd(self.y_out[:RM], self.p["decoder_norm.weight"], self.yn, self.st_dn[0], self.st_dn[1],
+                          out_row=self.perm, eps=cfg.eps)
+        self._have_fwd = True
+        if not need_loss:
+            return None
+
+        # ---- per-modality logits + CE (forward_mod_loss, egom2p_model.py:614-644)
+        for c, m in enumerate(mods):
+            l = self.lin[self.logit_key[m.name]]
+            ub = min(RM, B * m.max_tokens)
+            lg = self.logits[m.vocab_size]
+            ops.gemm_nt(self.yn, l.wb, lg, ub, m.vocab_size, D, L.EPI_BF16, m_range=self.ranges[c], lda=D, ldb=D, ldc=m.vocab_size)
+            ops.ce_fwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll)
+        ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out)
+        return self.loss_out[0], {m.name: self.loss_out[1 + c] for c, m in enumerate(mods)}
+
+    # ------------------------------------------------------------------------------------ backward
+    def _mlp_bwd(self, pre, w, dres, dres_b, rows, xin):
+        """residual-stream gradient through x + fc2(swiglu(fc13(LN2(x)))); xin = LN2 input (saved)."""
+        Fp = self.Fp
+        dh, dab, dln = self.t_f, self.t_2f, self.t_d
+        self._lin_bwd(f"{pre}.mlp.fc2.weight", dres_b, w["h"], dh, rows)
+        ops.swiglu_bwd(w["ab"], dh, dab, rows, Fp)
+        self._lin_bwd(f"{pre}.mlp.fc13", dab, w["ln2"], dln, rows)
+        ops.layernorm_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],
+                          dx_in=dres, dx_bf16=dres_b)
+
+    def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke):
+        D, B = self.D, self.B
+        dao, dqkv, dln = self.t_d, self.t_3d, self.t_d2
+        self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
+        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, Nq, 1, B, Nq, Nq)
+        self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
+        ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
+                          dx_in=dres, dx_bf16=dres_b)
+
+    def backward(self, gscale=1.0, bucket_done: Optional[Callable[[str, int, int], None]] = None):
+        """Backward of the last forward; gradients are ACCUMULATED into the flat grad buffer scaled by
+        `gscale` (float or 1-element device tensor: the upstream d loss).  `bucket_done(name, lo, hi)` is
+        called (in launch order) as soon as every kernel writing G[lo:hi] has been enqueued."""
+        assert self._have_fwd, "backward() needs a forward()"
+        cfg, D, N, M, B = self.cfg, self.D, self.N, self.M, self.B
+        RN, RM = B * N, B * M
+        mods, ce, cd = self.mods, self.ce, self.cd
+        if isinstance(gscale, torch.Tensor):
+            self.gscale.copy_(gscale.reshape(1).to(F32))
+        else:
+            self.gscale.fill_(float(gscale))
+        bmap = {n: (lo, hi) for n, lo, hi in self.buckets}
+
+        def done(name):
+            if bucket_done is not None:
+                lo, hi = bmap[name]
+                bucket_done(name, lo, hi)
+
+        # ---- loss head: d logits in place, d yn, d table (tied to_logits/token_emb)
+        for c, m in enumerate(mods):
+            l = self.lin[self.logit_key[m.name]]
+            ub = min(RM, B * m.max_tokens)
+            V = m.vocab_size
+            lg = self.logits[V]
+            ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods)
+            ops.gemm_nt(lg, l.wt, self.dyn, ub, D, V, L.EPI_BF16, m_range=self.ranges[c], lda=V, ldb=V, ldc=D)
+            ops.gemm_tn(lg, self.yn, l.g, V, D, ub, m_range=self.ranges[c], ldp=V, ldq=D, ldc=D)
+        for m in reversed(mods):
+            done(f"dec_table.{m.name}" if cfg.share_embedding else f"to_logits.{m.name}")
+        dres, dres_b = self.dres, self.dres_b
+        ops.layernorm_bwd(self.dyn, self.y_out[:RM], self.st_dn[0], self.st_dn[1], self.p["decoder_norm.weight"], dres,
+                          self.g["decoder_norm.weight"], dx_in=None, dx_bf16=dres_b, dy_row=self.perm)
+
+        # ---- decoder layers
+        first_ctx = True
+        for i in reversed(range(cfg.decoder_depth)):
+            w, pre = self.dec[i], f"decoder.{i}"
+            self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
+            # cross attention
+            dxo, dq, dkv, dln = self.t_d, self.t_d2, self.t_2d, self.t_d
+            self._lin_bwd(f"{pre}.cross_attn.proj.weight", dres_b, w["xo"], dxo, RM)
+            self._attn_bwd(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], dxo, w["lse_x"], dq, dkv, self.zero_b, ce["n_valid"],
+                           1, 0, B, M, N)
+            self._lin_bwd(f"{pre}.cross_attn.q.weight", dq, w["qn"], dln, RM)
+            ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
+                              self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=dres_b)
+            dcn = self.t_d2
+            self._lin_bwd(f"{pre}.cross_attn.kv.weight", dkv, w["cn"], dcn, RN)
+            ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
+                              self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx)
+            first_ctx = False
+            self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"])
+            done(pre)
+        if cfg.decoder_depth == 0:
+            self.dctx[:RN].zero_()
+        # decoder input embeddings: mask token + (pos + mod_emb)
+        dmods = self.dmods
+        ops.embed_bwd(None, [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods], self.g["mask_token"],
+                      dres, None, cd["slot"], cd["tok"], RM, D)
+        done("head")
+
+        # ---- context projection + encoder_norm
+        ops.cast_f32_bf16(self.dctx[:RN], self.dctx_b)
+        ops.bias_grad(self.dctx_b, RN, D, self.g["decoder_proj_context.bias"])
+        dxe_n = self.t_d
+        self._lin_bwd("decoder_proj_context.weight", self.dctx_b, self.xe, dxe_n, RN)
+        dxe, dxe_b = self.dxe, self.dxe_b
+        ops.layernorm_bwd(dxe_n, self.x_enc_out[:RN], self.st_en[0], self.st_en[1], self.p["encoder_norm.weight"], dxe,
+                          self.g["encoder_norm.weight"], dx_in=None, dx_bf16=dxe_b)
+        done("bridge")
+
+        # ---- encoder layers
+        for i in reversed(range(cfg.encoder_depth)):
+            w, pre = self.enc[i], f"encoder.{i}"
+            self._mlp_bwd(pre, w, dxe, dxe_b, RN, w["xm"])
+            self._self_attn_bwd(pre, "attn", w, dxe, dxe_b, RN, N, ce["ks"], ce["ke"])
+            done(pre)
+        # encoder input embeddings: token rows, mod_emb (emb is used twice: x = tok + emb and context += emb)
+        ops.embed_bwd([self.g[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
+                      [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, dxe, self.dctx,
+                      ce["slot"], ce["tok"], RN, D)
+        done("mod_emb")
+        for m in reversed(mods):
+            done(f"enc_table.{m.name}")
+        self._have_fwd = False
+
+    def zero_grad(self):
+        self.G.zero_()
