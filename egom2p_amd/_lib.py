@@ -83,6 +83,12 @@ def load():
             raise EgoHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C egom2p_amd/csrc`). There is no CPU fallback for the product path.")
+        # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE our library is
+        # dlopen'ed so both share one HIP runtime (streams and device pointers are per-runtime).
+        import torch
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
         lib = C.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             fn = getattr(lib, name)

@@ -225,18 +225,46 @@ class Engine:
         out["mask_token"] = self.p["mask_token"].view(1, 1, D)
         return out
 
-    def grad_of(self, key: str) -> torch.Tensor:
-        F = self.F
+    def _canon_key(self, key: str) -> str:
+        """reference state-dict key -> engine storage key (shared mod_emb, tied to_logits)."""
         if key.startswith("decoder_embeddings") and key.endswith("mod_emb"):
             key = key.replace("decoder_embeddings", "encoder_embeddings")
         if key.endswith("to_logits.weight") and self.cfg.share_embedding:
             key = key.replace("to_logits.weight", "token_emb.weight")
+        return key
+
+    def grad_of(self, key: str) -> torch.Tensor:
+        F = self.F
+        key = self._canon_key(key)
         t = self.g[key]
         if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
             return t[:F]
         if key.endswith("mlp.fc2.weight"):
             return t[:, :F]
         return t
+
+    @torch.no_grad()
+    def init_random(self, seed: int = 0):
+        """Random init in the reference's distributions (egom2p_model.py:185-222), drawn on the device:
+        xavier-uniform linears (qkv / kv as 3 / 2 matrices), N(0, 0.02) embeddings, LayerNorm weight 1."""
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(seed)
+        self.P.zero_()
+        for name in self.p:
+            v = self._view_for_key(name)
+            if name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token" or name.endswith("to_logits.weight"):
+                v.copy_(torch.randn(v.shape, device=self.dev, generator=gen) * 0.02)
+            elif name.endswith("norm.weight") or ".norm" in name:
+                v.fill_(1.0)
+            elif name.endswith(".bias"):
+                v.zero_()
+            else:
+                fo, fi = v.shape
+                if "qkv" in name: fo //= 3
+                elif "kv" in name: fo //= 2
+                a = math.sqrt(6.0 / (fo + fi))
+                v.copy_((torch.rand(v.shape, device=self.dev, generator=gen) * 2 - 1) * a)
+        self.weights_dirty = True
 
     def param_names(self) -> List[str]:
         return list(self.p.keys())
@@ -354,7 +382,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
-                need_loss: bool = True):
+                need_loss: bool = True, group_rows: bool = True):
         """Forward of one micro-batch (tensors already on the device).  Returns (loss, {mod: loss}) as
         views of a device buffer: reading them is the only host sync."""
         if self.weights_dirty:
@@ -429,7 +457,7 @@ class Engine:
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RM, L.EPI_RESID, R=w["x2"])
         # decoder_norm, rows written modality-grouped (the row order of y[decoder_mod_mask == id], :633)
         ops.layernorm_fwd(self.y_out[:RM], self.p["decoder_norm.weight"], self.yn, self.st_dn[0], self.st_dn[1],
-                          out_row=self.perm, eps=cfg.eps)
+                          out_row=self.perm if group_rows else None, eps=cfg.eps)
         self._have_fwd = True
         if not need_loss:
             return None
@@ -553,3 +581,24 @@ class Engine:
 
     def zero_grad(self):
         self.G.zero_()
+
+    def resize_workspaces(self, max_batch: int, n_enc: int, n_dec: int):
+        """Re-allocate the activation workspaces for another (batch, N, M); parameters are untouched."""
+        self.Bmax, self.N, self.M = max_batch, n_enc, n_dec
+        self._alloc_workspaces()
+        self._have_fwd = False
+
+    @torch.no_grad()
+    def forward_logits(self, mod_dict, dec_order=None) -> Dict[str, torch.Tensor]:
+        """`return_logits=True` path of EgoM2P.forward (egom2p_model.py:727-729, 546-547): logits of every
+        decoder row for every modality, (B, M, V) bf16."""
+        self.forward(mod_dict, dec_order=dec_order, need_loss=False, group_rows=False)
+        B, M, D = self.B, self.M, self.D
+        out = {}
+        for m in self.mods:
+            l = self.lin[self.logit_key[m.name]]
+            lg = torch.empty(B * M, m.vocab_size, device=self.dev, dtype=BF16)
+            ops.gemm_nt(self.yn, l.wb, lg, B * M, m.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=m.vocab_size)
+            out[m.name] = lg.view(B, M, m.vocab_size)
+        self._have_fwd = False
+        return out

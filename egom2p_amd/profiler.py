@@ -1,0 +1,123 @@
+"""Live per-kernel-class timing with HIP events on the launch stream (the engine launches on torch's
+current stream, so `torch.cuda.Event` brackets exactly the kernels of one C-ABI call) plus the
+algorithmic FLOP / byte counts of each call.  Used by bench.py for the `roofline` object; the same
+command under `rocprofv3 --kernel-trace --stats` gives the cross-check committed under profiles/.
+"""
+from __future__ import annotations
+
+import contextlib
+from collections import defaultdict
+from typing import Dict
+
+import torch
+
+from . import ops
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
+
+
+class KernelTimer:
+    def __init__(self):
+        self.records = []      # (class, flops, bytes, start_event, end_event)
+
+    def _wrap(self, name, fn, cost):
+        def wrapped(*a, **k):
+            flops, nbytes = cost(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            self.records.append((name, flops, nbytes, s, e))
+            return r
+        return wrapped
+
+    @contextlib.contextmanager
+    def capture(self, H: int):
+        def rows_of(m_range, M):
+            return int(m_range[1].item()) if m_range is not None else M
+
+        def c_gemm_nt(A, B, C, M, N, K, epi=0, R=None, bias=None, m_range=None, **kw):
+            m = min(M, rows_of(m_range, M))
+            return 2.0 * m * N * K, 2.0 * (m * K + N * K) + (2.0 if epi == 0 else 8.0) * m * N
+
+        def c_gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_range=None, **kw):
+            m = min(M, rows_of(m_range, M))
+            return 2.0 * m * Ni * Nj, 2.0 * m * (Ni + Nj) + 8.0 * Ni * Nj
+
+        def _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk):
+            if r_rs == 0:
+                n = (ke[:B].clamp(max=Nk) - ks[:B]).clamp(min=0).double().sum().item() * Nq
+            else:
+                n = (ke[:B].clamp(max=Nk) - ks[:B]).clamp(min=0).double().sum().item()
+            return n
+
+        def c_attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, Hh, Nq, Nk, scale):
+            p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
+            return 4.0 * 64 * Hh * p, 2.0 * B * Hh * 64 * (2 * Nq + 2 * Nk)
+
+        def c_attn_bwd(*a):
+            ks, ke, r_bs, r_rs, B, Hh, Nq, Nk = a[-9], a[-8], a[-7], a[-6], a[-5], a[-4], a[-3], a[-2]
+            p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
+            return 10.0 * 64 * Hh * p, 2.0 * B * Hh * 64 * (4 * Nq + 4 * Nk)
+
+        def rowcost(bytes_per_row_elem):
+            def c(*a, **k):
+                return 0.0, 0.0
+            return c
+
+        def c_ln_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6):
+            return 0.0, x.shape[0] * x.shape[1] * 6.0
+
+        def c_ln_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
+            n = x.shape[0] * x.shape[1]
+            return 0.0, n * (2.0 + 4.0 + 4.0 + (4.0 if dx_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0))
+
+        def c_swiglu_fwd(ab, h, rows, F):
+            return 0.0, rows * F * 6.0
+
+        def c_swiglu_bwd(ab, dh, dab, rows, F):
+            return 0.0, rows * F * 10.0
+
+        def c_ce(logits, ld, V, targets, rng, max_rows, *a):
+            n = int(rng[1].item())
+            return 0.0, n * V * 2.0
+
+        def c_ce_bwd(logits, ld, V, targets, rng, max_rows, *a):
+            n = int(rng[1].item())
+            return 0.0, n * V * 4.0
+
+        table = {
+            "gemm_nt": c_gemm_nt, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
+            "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
+            "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
+        }
+        other = ["compact", "embed_fwd", "embed_bwd", "loss_perm", "loss_finalize", "cast_weight", "cast_f32_bf16",
+                 "bias_grad", "grad_sqnorm", "adamw_step"]
+        saved = {}
+        for name, cost in table.items():
+            saved[name] = getattr(ops, name)
+            setattr(ops, name, self._wrap(name, saved[name], cost))
+        for name in other:
+            saved[name] = getattr(ops, name)
+            setattr(ops, name, self._wrap("other:" + name, saved[name], lambda *a, **k: (0.0, 0.0)))
+        try:
+            yield self
+        finally:
+            for name, fn in saved.items():
+                setattr(ops, name, fn)
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "calls": 0})
+        for name, fl, nb, s, e in self.records:
+            a = agg[name]
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += fl
+            a["bytes"] += nb
+            a["calls"] += 1
+        out = {}
+        for name, a in agg.items():
+            sec = a["ms"] * 1e-3
+            out[name] = dict(a, tflops=(a["flops"] / sec / 1e12 if sec > 0 else 0.0), gbs=(a["bytes"] / sec / 1e9 if sec > 0 else 0.0))
+        return out
