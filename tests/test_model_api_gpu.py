@@ -1,0 +1,105 @@
+"""The drop-in module surface on the GPU: `EgoM2P` / `create_model` / `create_optimizer` /
+`NativeScalerWithGradNormCount` / `DataParallel` used the way run_training_egom2p.py uses the reference's
+(`:381-387, 514-518, 723-741`), checked against the reference goldens."""
+import random
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, rel_l2  # noqa: E402
+from egom2p_amd import synth  # noqa: E402
+from egom2p_amd.config import MODEL_CFGS  # noqa: E402
+from egom2p_amd.dp import DataParallel  # noqa: E402
+from egom2p_amd.model import (MODALITY_INFO, EgoM2P, LayerNorm, create_model, list_models)  # noqa: E402
+from egom2p_amd.optim import NativeScalerWithGradNormCount, create_optimizer  # noqa: E402
+
+
+def _tiny_model():
+    mods = ["tok_cam", "tok_gaze"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    return EgoM2P(enc, dec, {m: MODALITY_INFO[m] for m in mods}, dim=128, encoder_depth=2, decoder_depth=2, num_heads=2,
+                  mlp_ratio=4, qkv_bias=False, proj_bias=False, mlp_bias=False,
+                  norm_layer=partial(LayerNorm, eps=1e-6, bias=False), act_layer=nn.SiLU, gated_mlp=True)
+
+
+def test_module_forward_backward_step_matches_reference():
+    g, meta = load_golden("tiny_pad")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    model = _tiny_model()
+    # state-dict key layout is the reference's
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.float().cpu().reshape(sd[k].shape), sd[k]), k
+    ddp = DataParallel(model)                           # single process: passthrough with .module / no_sync()
+    args = types.SimpleNamespace(opt="adamw", lr=meta["lr"], weight_decay=meta["wd"], opt_betas=(0.9, 0.95), opt_eps=1e-8)
+    opt = create_optimizer(args, ddp.module)
+    scaler = NativeScalerWithGradNormCount(enabled=False)
+
+    random.seed(meta["py_seed"])                        # same python-random state as the golden run -> same decoder order
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    loss, mod_loss = ddp(mdg, num_encoder_tokens=meta["n_enc"], num_decoder_tokens=meta["n_dec"], loss_type="mod")
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * float(g["loss"])
+    for m in cfg.mods:
+        assert abs(mod_loss[m.name].item() - float(g[f"mod_loss.{m.name}"])) < 1e-3 * max(1.0, float(g[f"mod_loss.{m.name}"]))
+    opt.zero_grad()
+    norm = scaler(loss, opt, clip_grad=1.0, parameters=ddp.parameters(), update_grad=True)
+    assert abs(norm.item() - float(g["clip_total_norm"])) < 2e-2 * float(g["clip_total_norm"])
+    new = model.state_dict()
+    for key in g.files:
+        if key.startswith("adamw."):
+            n = key.split(".", 1)[1]
+            assert np.abs(new[n].float().cpu().numpy().reshape(g[key].shape) - g[key]).max() <= 2.2 * meta["lr"], n
+    # the fused step zeroed the gradients (zero_grad folded in)
+    assert float(model.engine.G.abs().max().item()) == 0.0
+
+
+def test_gradients_visible_through_param_grad_and_no_sync_accumulates():
+    g, meta = load_golden("tiny")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    model = _tiny_model()
+    model.load_state_dict(sd)
+    ddp = DataParallel(model)
+    named = dict(model.named_parameters())
+    for rep in range(2):
+        random.seed(meta["py_seed"])
+        with ddp.no_sync():
+            loss, _ = ddp(mdg, meta["n_enc"], meta["n_dec"])
+            (loss / 2).backward()
+    coef = min(1.0, 1.0 / (float(g["clip_total_norm"]) + 1e-6))
+    for key in g.files:
+        if key.startswith("grad."):
+            n = key[5:]
+            got = named[n].grad.float().cpu().numpy().reshape(g[key].shape) * coef      # two half-weighted passes = one
+            assert rel_l2(got, g[key]) < 4e-2, (n, rel_l2(got, g[key]))
+
+
+def test_registry_and_scope_errors():
+    assert "egom2p_base_12e_12d_swiglu_nobias" in list_models()
+    mods = ["tok_rgb", "tok_depth", "tok_cam", "tok_gaze"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    model = create_model("egom2p_tiny_6e_6d_swiglu_nobias", encoder_embeddings=enc, decoder_embeddings=dec,
+                         modality_info=MODALITY_INFO, num_register_tokens=0)
+    n = sum(p.numel() for p in model.parameters())
+    assert n == model.engine.num_params()
+    with pytest.raises(NotImplementedError):
+        create_model("egom2p_base_12e_12d_gelu", encoder_embeddings=enc, decoder_embeddings=dec, modality_info=MODALITY_INFO)
+    # eval / return_logits path
+    md = synth.make_clip_batch(MODEL_CFGS["ego_b_2e_2d"], 1, None, seed=9)
+    with torch.no_grad():
+        logits = model({k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}, 256, 256, return_logits=True)
+    assert logits["tok_rgb"].shape == (1, 256, 64000) and logits["tok_cam"].shape == (1, 256, 256)
+    assert torch.isfinite(logits["tok_rgb"].float()).all()
