@@ -5,24 +5,26 @@
 //   gemm_tn : C[Ni,Nj] += P[M,Ni]^T . Q[M,Nj]   wgrad (P = dY, Q = layer input), contraction over rows
 //
 // Both: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave as 4x4
-// v_mfma_f32_16x16x32_bf16 tiles), 64-deep contraction steps, double-buffered LDS with register
-// staging (global loads for step t+1 issued before the MFMAs of step t, written to the other
-// LDS buffer after them: one barrier per step).  LDS images are XOR-swizzled so that the
-// ds_read_b128 row reads (nt) and the ds_read_b64_tr_b16 transposed reads (tn) are bank-conflict
-// free.  The accumulator is produced transposed (operands swapped in the MFMA) so each lane owns
-// 4 consecutive output columns -> 8/16-byte stores.
+// v_mfma_f32_16x16x32_bf16 tiles), 64-deep contraction steps, two LDS stages filled by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write), the load of step t+1 in flight under the
+// MFMAs of step t, one barrier per step.  LDS images are XOR-swizzled - on the DMA *source* address,
+// because the DMA destination is lane-linear - so that the ds_read_b128 row reads (nt) and the
+// ds_read_b64_tr_b16 transposed reads (tn) are bank-conflict free.  The accumulator is produced
+// transposed (operands swapped in the MFMA) so each lane owns 4 consecutive output columns.
 //
 // Replaces: torch.nn.functional.linear under autocast(bf16) at every call site of
 // egom2p/models/egom2p_utils.py:141-169,180-203,215-242 and decoder_embeddings.py:372-383,489-500,
 // and their autograd backward (mm dgrad / wgrad).
 #include "common.h"
 #include "egom2p_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = 2 * BM * BK * 2;   // A tile + B tile (bf16) = 32 KiB
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB
+constexpr int TILE_BYTES = BM * BK * 2;        // one operand tile (bf16) = 16 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A tile + B tile = 32 KiB
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB -> 2 workgroups per CU
 
 struct NTArgs {
     const bf16_t* A; long lda;
@@ -34,114 +36,174 @@ struct NTArgs {
     int M, N, K, epi;
 };
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt (its fence covers
+// global memory), which would expose the completion latency of the epilogue's global stores on every tile
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    // 16 B per lane straight into LDS (LDS-DMA): dst = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
-// NT kernel
+// NT kernel, persistent.  Each workgroup walks a strided list of 128x128 output tiles; the K loop runs
+// as ONE pipeline across tile boundaries (the first K-step of the next tile is loaded under the last
+// K-step of the current one), so only the very first load of a workgroup is exposed.  That matters
+// here: most of the model's GEMMs have K = 768 = 12 steps.  Tile ownership is XCD-aware: the 64
+// workgroups that share an XCD's L2 work on 64 consecutive tiles (same A row panel / neighbouring B
+// panels) - speed only, never correctness.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     int M = p.M;
     long moff = 0;
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
+    if (M <= 0) return;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int row0 = (t / tiles_n) * BM, col0 = (t % tiles_n) * BN;
-    if (row0 >= M) return;
-
-    const bf16_t* A = p.A + moff * p.lda;
-    const bf16_t* B = p.B;
-
-    // staging map: chunk q = tid + 256*i -> tile row q>>3, 16-byte chunk q&7
-    u32x4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int ar = row0 + r, br = col0 + r;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            ra[i] = (ar < M) ? *(const u32x4*)(A + (long)ar * p.lda + k0 + c * 8) : z;
-            rb[i] = (br < p.N) ? *(const u32x4*)(B + (long)br * p.ldb + k0 + c * 8) : z;
-        }
-    };
-    auto store_tile = [&](int s) {
-        char* sa = smem + s * STAGE_BYTES;
-        char* sb = sa + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int off = r * 128 + ((c ^ (r & 7)) << 4);
-            *(u32x4*)(sa + off) = ra[i];
-            *(u32x4*)(sb + off) = rb[i];
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    const int ntiles = ((M + BM - 1) / BM) * tiles_n;       // tiles that exist (M may come from the device)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nslot = (gridDim.x + 7 - xcd) >> 3;           // workgroups with this blockIdx & 7
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_hi = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + slot;
+    if (tile >= t_hi) return;
     const int nt = p.K / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-        const int s = kt & 1;
-        if (kt + 1 < nt) load_tile((kt + 1) * BK);
-        const char* sa = smem + s * STAGE_BYTES;
-        const char* sb = sa + BM * BK * 2;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
-            const int c = ks * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ar = wm * 64 + i * 16 + (lane & 15);
-                af[i] = *(const bf16x8*)(sa + ar * 128 + ((c ^ (ar & 7)) << 4));
-                const int br = wn * 64 + i * 16 + (lane & 15);
-                bfr[i] = *(const bf16x8*)(sb + br * 128 + ((c ^ (br & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    // operands swapped: D[row = n (4 regs)][col = m (lane&15)]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nt) store_tile(s ^ 1);
-        __syncthreads();
-    }
 
-    // epilogue: lane owns row m, columns n..n+3
+    // Staging map: wave instruction (wave*4 + j) writes 1 KiB = tile rows 8(wave*4+j) .. +7, 128 B each,
+    // lane-linear; slot s of row r holds global chunk s ^ (r & 7).  Rows beyond M / N are clamped to the
+    // last valid row: they only feed output rows / columns that are never stored.
+    int lr[4], lc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = row0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= M) continue;
-        const long mrow = moff + m;
+    for (int j = 0; j < 4; ++j) {
+        lr[j] = 8 * (wave * 4 + j) + (lane >> 3);
+        lc[j] = ((lane & 7) ^ (lr[j] & 7)) * 8;
+    }
+    auto stage = [&](int s, int tl, int k0) {
+        const int row0 = (tl / tiles_n) * BM, col0 = (tl % tiles_n) * BN;
+        char* sa = smem + s * STAGE_BYTES + wave * 4096;
+        char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = col0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if (p.epi == EGO_EPI_BF16) {
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)p.C + mrow * p.ldc + n) = o;
-            } else if (p.epi == EGO_EPI_F32) {
-                *(f32x4*)((float*)p.C + mrow * p.ldc + n) = v;
-            } else if (p.epi == EGO_EPI_RESID) {
-                const f32x4 r = *(const f32x4*)(p.R + mrow * p.ldr + n);
-                f32x4 o = {r[0] + round_bf16(v[0]), r[1] + round_bf16(v[1]), r[2] + round_bf16(v[2]), r[3] + round_bf16(v[3])};
-                *(f32x4*)((float*)p.C + mrow * p.ldc + n) = o;
-            } else {  // EGO_EPI_BIAS_RESID
-                const f32x4 r = *(const f32x4*)(p.R + mrow * p.ldr + n);
-                const f32x4 b = *(const f32x4*)(p.bias + n);
-                f32x4 o = {r[0] + round_bf16(v[0] + round_bf16(b[0])), r[1] + round_bf16(v[1] + round_bf16(b[1])),
-                           r[2] + round_bf16(v[2] + round_bf16(b[2])), r[3] + round_bf16(v[3] + round_bf16(b[3]))};
-                *(f32x4*)((float*)p.C + mrow * p.ldc + n) = o;
+            glds16(p.A + (moff + min(row0 + lr[j], M - 1)) * p.lda + lc[j] + k0, sa + j * 1024);
+            glds16(p.B + (long)min(col0 + lr[j], p.N - 1) * p.ldb + lc[j] + k0, sb + j * 1024);
+        }
+    };
+
+    stage(0, tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int next_tile = tile + nslot;
+        const bool more = next_tile < t_hi;
+        for (int kt = 0; kt < nt; ++kt) {
+            if (kt + 1 < nt) stage(cur ^ 1, tile, (kt + 1) * BK);
+            else if (more) stage(cur ^ 1, next_tile, 0);
+            const char* sa = smem + cur * STAGE_BYTES;
+            const char* sb = sa + TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[4];
+                const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ar = wm * 64 + i * 16 + (lane & 15);
+                    af[i] = *(const bf16x8*)(sa + ar * 128 + ((c ^ (ar & 7)) << 4));
+                    const int br = wn * 64 + i * 16 + (lane & 15);
+                    bfr[i] = *(const bf16x8*)(sb + br * 128 + ((c ^ (br & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        // operands swapped: D[row = n (4 regs)][col = m (lane&15)]
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        // Epilogue through LDS.  The next tile's first K-step already sits in stage `cur`; stage `cur ^ 1` is
+        // free: the accumulators are transposed through it so that every wave store instruction writes whole
+        // contiguous rows (4 rows x 256 B) instead of 16 scattered 32-byte pieces - on the K = 768 shapes the
+        // scattered form cost ~30 % of the kernel.  16-byte chunk c of tile row r sits at chunk c ^ (r & 15).
+        const int row0 = (tile / tiles_n) * BM, col0 = (tile % tiles_n) * BN;
+        char* ebuf = smem + (cur ^ 1) * STAGE_BYTES;
+        if (p.epi == EGO_EPI_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = wn * 16 + j * 4 + (lane >> 4);          // 8-byte slot (4 bf16) in the row
+                    const f32x4 v = acc[i][j];
+                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2*)(ebuf + ml * 256 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int r = ps * 16 + (tid >> 4), c = tid & 15;
+                const u32x4 v = *(const u32x4*)(ebuf + r * 256 + ((c ^ (r & 15)) << 4));
+                const int gm = row0 + r, gn = col0 + c * 8;
+                if (gm < M && gn < p.N) *(u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn) = v;
+            }
+            lds_barrier();
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                          // 64 rows x 128 fp32 = 32 KiB per pass
+                if (wm == half) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ml = i * 16 + (lane & 15);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = wn * 16 + j * 4 + (lane >> 4);    // 16-byte chunk (4 fp32) in the row
+                            *(f32x4*)(ebuf + ml * 512 + ((c ^ (ml & 15)) << 4)) = acc[i][j];
+                        }
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int r = ps * 8 + (tid >> 5), c = tid & 31;
+                    f32x4 v = *(const f32x4*)(ebuf + r * 512 + ((c ^ (r & 15)) << 4));
+                    const int gm = row0 + half * 64 + r, gn = col0 + c * 4;
+                    if (gm < M && gn < p.N) {
+                        const long mrow = moff + gm;
+                        if (p.epi == EGO_EPI_RESID) {
+                            const f32x4 rr = *(const f32x4*)(p.R + mrow * p.ldr + gn);
+                            v = f32x4{rr[0] + round_bf16(v[0]), rr[1] + round_bf16(v[1]), rr[2] + round_bf16(v[2]), rr[3] + round_bf16(v[3])};
+                        } else if (p.epi == EGO_EPI_BIAS_RESID) {
+                            const f32x4 rr = *(const f32x4*)(p.R + mrow * p.ldr + gn);
+                            const f32x4 b = *(const f32x4*)(p.bias + gn);
+                            v = f32x4{rr[0] + round_bf16(v[0] + round_bf16(b[0])), rr[1] + round_bf16(v[1] + round_bf16(b[1])),
+                                      rr[2] + round_bf16(v[2] + round_bf16(b[2])), rr[3] + round_bf16(v[3] + round_bf16(b[3]))};
+                        }
+                        *(f32x4*)((float*)p.C + mrow * p.ldc + gn) = v;
+                    }
+                }
+                lds_barrier();
             }
         }
+        if (!more) break;
+        tile = next_tile;
     }
 }
 
@@ -162,9 +224,59 @@ struct TNArgs {
 // a transposed read ({0..3, 8..11} + 16h, or +4) must land on 8 different 32-byte bank groups.
 __device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
+// ds_read_b64_tr_b16 as inline asm: hipcc orders its own builtin form behind `vmcnt(0)` whenever an
+// LDS-DMA is in flight (it cannot prove the DMA targets the other stage), which serialises load and
+// compute; the asm form is invisible to that pass.  Its completion is therefore OUR job: every use is
+// behind an explicit `s_waitcnt lgkmcnt(0)` + sched_barrier (cdna_hip_programming.md 5.7 item 1, rule 18).
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int S>   // LDS stage
+__device__ __forceinline__ void tn_compute(const unsigned (&pb)[4], const unsigned (&qb)[4], f32x4 (&acc)[4][4]) {
+    constexpr int O = S * STAGE_BYTES;
+    s16x4 p0[4][2], q0[4][2], p1[4][2], q1[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // k-step 0: tile rows 0..31
+        p0[i][0] = tr_read<O>(pb[i]);              p0[i][1] = tr_read<O + 1024>(pb[i]);
+        q0[i][0] = tr_read<O + TILE_BYTES>(qb[i]); q0[i][1] = tr_read<O + TILE_BYTES + 1024>(qb[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // k-step 1: tile rows 32..63, in flight under the MFMAs of k-step 0
+        p1[i][0] = tr_read<O + 8192>(pb[i]);              p1[i][1] = tr_read<O + 8192 + 1024>(pb[i]);
+        q1[i][0] = tr_read<O + TILE_BYTES + 8192>(qb[i]); q1[i][1] = tr_read<O + TILE_BYTES + 8192 + 1024>(qb[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            // D[row = j (4 regs)][col = i (lane&15)]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(q0[j][0], q0[j][1]), join8(p0[i][0], p0[i][1]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(q1[j][0], q1[j][1]), join8(p1[i][0], p1[i][1]), acc[i][j], 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
 
     int M = p.M;
@@ -185,29 +297,54 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
     const bf16_t* P = p.P + moff * p.ldp + i0;
     const bf16_t* Q = p.Q + moff * p.ldq + j0;
 
-    // staging: chunk q = tid + 256*i -> tile row q>>4 (0..63), 16-byte chunk q&15
-    u32x4 rp[4], rq[4];
-    auto load_tile = [&](int m0) {
+    // Staging by LDS-DMA: one wave instruction = 1 KiB = 4 tile rows x 256 B, lane-linear, 32-byte chunk
+    // swizzle applied to the SOURCE address.  A 64-row step that crosses M (rows there must contribute
+    // zero - clamping is not enough) is staged through registers with zero fill: at most one step.
+    long p_off[4], q_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * (wave * 4 + j) + (lane >> 4), s16 = lane & 15;
+        const int c = (((s16 >> 1) ^ tn_f(r)) << 1) | (s16 & 1);
+        p_off[j] = (long)r * p.ldp + c * 8;
+        q_off[j] = (long)r * p.ldq + c * 8;
+    }
+    auto stage_dma = [&](int s, int m0) {
+        char* sp = smem + s * STAGE_BYTES + wave * 4096;
+        char* sq = sp + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(P + (long)m0 * p.ldp + p_off[j], sp + j * 1024);
+            glds16(Q + (long)m0 * p.ldq + q_off[j], sq + j * 1024);
+        }
+    };
+    auto stage_regs = [&](int s, int m0) {
+        char* sp = smem + s * STAGE_BYTES;
+        char* sq = sp + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + 256 * i, r = q >> 4, c = q & 15;
             const int m = m0 + r;
             const u32x4 z = {0u, 0u, 0u, 0u};
-            rp[i] = (m < M) ? *(const u32x4*)(P + (long)m * p.ldp + c * 8) : z;
-            rq[i] = (m < M) ? *(const u32x4*)(Q + (long)m * p.ldq + c * 8) : z;
-        }
-    };
-    auto store_tile = [&](int s) {
-        char* sp = smem + s * STAGE_BYTES;
-        char* sq = sp + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, r = q >> 4, c = q & 15;
+            const u32x4 vp = (m < M) ? *(const u32x4*)(P + (long)m * p.ldp + c * 8) : z;
+            const u32x4 vq = (m < M) ? *(const u32x4*)(Q + (long)m * p.ldq + c * 8) : z;
             const int off = r * 256 + ((((c >> 1) ^ tn_f(r)) << 5) | ((c & 1) << 4));
-            *(u32x4*)(sp + off) = rp[i];
-            *(u32x4*)(sq + off) = rq[i];
+            *(u32x4*)(sp + off) = vp;
+            *(u32x4*)(sq + off) = vq;
         }
     };
+
+    // per-lane LDS byte addresses of the transposed-read blocks (k-step 0, rows 8g+q; +1024 B = rows +4,
+    // +8192 B = k-step 1, + stage / operand offsets are immediates): lane 4q+p of a 16-lane group supplies
+    // row q, columns 4p..4p+3 of a 4x16 block
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int r0 = 8 * g + tq;
+    unsigned pb[4], qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pb[i] = lds0 + r0 * 256 + (((wi * 4 + i) ^ tn_f(r0)) << 5) + tp * 8;
+        qb[i] = lds0 + r0 * 256 + (((wj * 4 + i) ^ tn_f(r0)) << 5) + tp * 8;
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -215,45 +352,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (st0 < st1) {
-        load_tile(st0 * BK);
-        store_tile(0);
+    // full 64-row steps: LDS-DMA, double buffered, the load of step t+1 in flight under the MFMAs of step t
+    const int st_full = min(st1, M / BK);             // steps [st0, st_full) have all 64 rows valid
+    if (st0 < st_full) {
+        stage_dma(0, st0 * BK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int st = st0; st < st1; ++st) {
-            const int s = (st - st0) & 1;
-            if (st + 1 < st1) load_tile((st + 1) * BK);
-            const char* sp = smem + s * STAGE_BYTES;
-            const char* sq = sp + BM * BK * 2;
-            const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf[4], qf[4];
-                const int r0 = ks * 32 + 8 * g + tq;       // rows for elements 0..3; +4 for 4..7
-                const int r1 = r0 + 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ci = wi * 4 + i;              // 32-byte chunk (16 columns) of the P image
-                    const int cj = wj * 4 + i;
-                    s16x4 a0 = lds_read_tr16(sp + r0 * 256 + ((ci ^ tn_f(r0)) << 5) + tp * 8);
-                    s16x4 a1 = lds_read_tr16(sp + r1 * 256 + ((ci ^ tn_f(r1)) << 5) + tp * 8);
-                    s16x4 b0 = lds_read_tr16(sq + r0 * 256 + ((cj ^ tn_f(r0)) << 5) + tp * 8);
-                    s16x4 b1 = lds_read_tr16(sq + r1 * 256 + ((cj ^ tn_f(r1)) << 5) + tp * 8);
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    pf[i] = __builtin_bit_cast(bf16x8, a);
-                    qf[i] = __builtin_bit_cast(bf16x8, b);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        // D[row = j (4 regs)][col = i (lane&15)]
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
-            }
-            if (st + 1 < st1) store_tile(s ^ 1);
+        for (int st = st0; st < st_full; st += 2) {
+            if (st + 1 < st_full) stage_dma(1, (st + 1) * BK);
+            tn_compute<0>(pb, qb, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (st + 1 >= st_full) break;
+            if (st + 2 < st_full) stage_dma(0, (st + 2) * BK);
+            tn_compute<1>(pb, qb, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+    }
+    // the (at most one) step that crosses M: zero-filled through registers
+    for (int st = max(st0, st_full); st < st1; ++st) {
+        stage_regs(0, st * BK);
+        __syncthreads();
+        tn_compute<0>(pb, qb, acc);
+        __syncthreads();
     }
 
 #pragma unroll
@@ -293,11 +415,13 @@ __global__ void tn_reduce_kernel(const float* slab, float* C0, float* C1, long l
     }
 }
 
+int g_nt_wgs = 512;        // persistent grid: 2 workgroups (64 KiB LDS each) per CU x 256 CUs
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
-    hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
     g_attr_done = true;
 }
 
@@ -308,12 +432,13 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
                                 int M, int N, int K, int epi, hipStream_t stream) {
     if (M <= 0 || N <= 0) return EGO_OK;
     if (K <= 0 || K % BK || N % 8 || lda % 8 || ldb % 8 || ldc % 4 || epi < 0 || epi > EGO_EPI_BIAS_RESID) return EGO_ERR_ARG;
+    if (epi == EGO_EPI_BF16 && ldc % 8) return EGO_ERR_ARG;
     if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS, stream, a);
+    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), GEMM_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

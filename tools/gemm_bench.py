@@ -1,0 +1,43 @@
+"""GEMM microbenchmark on the engine's shapes (random bf16 data, HIP-event timing on the launch stream).
+   EGO_GEMM_NT_VARIANT=k python tools/gemm_bench.py"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from egom2p_amd import ops, _lib as L
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+def main():
+    dev = "cuda"
+    res = {}
+    nt_shapes = [(32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (32768, 768, 4096),
+                 (16144, 64000, 768), (16144, 768, 64000), (4096, 4096, 4096), (8192, 8192, 8192)]
+    for M, N, K in nt_shapes:
+        A = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+        B = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
+        C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16))
+        res[f"nt {M}x{N}x{K}"] = round(2.0 * M * N * K / t / 1e12, 1)
+        del A, B, C
+    if os.environ.get("SKIP_TN") != "1":
+        slab = torch.empty(48 * 1024 * 1024 // 4, device=dev)
+        for M, Ni, Nj in [(32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (16144, 64000, 768)]:
+            P = (torch.rand(M, Ni, device=dev) * 2 - 1).bfloat16()
+            Q = (torch.rand(M, Nj, device=dev) * 2 - 1).bfloat16()
+            C = torch.zeros(Ni, Nj, device=dev)
+            tiles = (Ni // 128) * (Nj // 128)
+            splits = max(1, min((M + 63) // 64, (512 + tiles - 1) // tiles, slab.numel() // (Ni * Nj)))
+            t = timeit(lambda: ops.gemm_tn(P, Q, C, Ni, Nj, M, splits=splits, slab=slab if splits > 1 else None))
+            res[f"tn {M}x{Ni}x{Nj} s{splits}"] = round(2.0 * M * Ni * Nj / t / 1e12, 1)
+            del P, Q, C
+    print(json.dumps({"variant": os.environ.get("EGO_GEMM_NT_VARIANT", "0"), **res}))
+
+if __name__ == "__main__":
+    main()
