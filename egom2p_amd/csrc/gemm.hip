@@ -24,7 +24,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // one operand tile (bf16) = 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A tile + B tile = 32 KiB
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB -> 2 workgroups per CU
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB (tn kernel)
+constexpr int EPI_BYTES = 16 * 1024;           // nt kernel: epilogue scratch behind the two stages
+constexpr int NT_LDS = GEMM_LDS + EPI_BYTES;   // 80 KiB -> exactly 2 workgroups per CU (160 KiB)
 
 struct NTArgs {
     const bf16_t* A; long lda;
@@ -100,8 +102,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 
     stage(0, tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    lds_barrier();
     int cur = 0;
+    bool pre = false;          // K-step 1 of this tile was already issued behind the previous tile's last barrier
+    bool pre_counted = false;  // ... and exactly 8 younger store instructions of this wave sit behind it
     while (true) {
         f32x4 acc[4][4];
 #pragma unroll
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         const int next_tile = tile + nslot;
         const bool more = next_tile < t_hi;
         for (int kt = 0; kt < nt; ++kt) {
-            if (kt + 1 < nt) stage(cur ^ 1, tile, (kt + 1) * BK);
+            if (kt == 0 && pre) { /* in flight */ }
+            else if (kt + 1 < nt) stage(cur ^ 1, tile, (kt + 1) * BK);
             else if (more) stage(cur ^ 1, next_tile, 0);
             const char* sa = smem + cur * STAGE_BYTES;
             const char* sb = sa + TILE_BYTES;
@@ -133,39 +138,58 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
                         // operands swapped: D[row = n (4 regs)][col = m (lane&15)]
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // the stage issued for the next step must have landed.  vmcnt is in issue order and counts stores
+            // too: after a prefetched step the 8 epilogue stores of this wave are YOUNGER than the DMA we need,
+            // so they may stay in flight (their completion latency was the largest epilogue cost).
+            if (kt == 0 && pre_counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
             cur ^= 1;
         }
+        pre = false;
+        pre_counted = false;
 
         // Epilogue through LDS.  The next tile's first K-step already sits in stage `cur`; stage `cur ^ 1` is
         // free: the accumulators are transposed through it so that every wave store instruction writes whole
         // contiguous rows (4 rows x 256 B) instead of 16 scattered 32-byte pieces - on the K = 768 shapes the
         // scattered form cost ~30 % of the kernel.  16-byte chunk c of tile row r sits at chunk c ^ (r & 15).
         const int row0 = (tile / tiles_n) * BM, col0 = (tile % tiles_n) * BN;
-        char* ebuf = smem + (cur ^ 1) * STAGE_BYTES;
         if (p.epi == EGO_EPI_BF16) {
+            // stage `cur` holds the next tile's K-step 0; put its K-step 1 in flight NOW (stage cur^1 is free)
+            // and run the epilogue through the dedicated scratch, two 64-row halves of 16 KiB
+            if (more && nt >= 2) {
+                stage(cur ^ 1, next_tile, BK);
+                pre = true;
+                pre_counted = (row0 + BM <= M) && (col0 + BN <= p.N);     // all 8 stores below really issue
+            }
+            char* ebuf = smem + GEMM_LDS;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = wm * 64 + i * 16 + (lane & 15);
+            for (int half = 0; half < 2; ++half) {
+                if (wm == half) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int slot = wn * 16 + j * 4 + (lane >> 4);          // 8-byte slot (4 bf16) in the row
-                    const f32x4 v = acc[i][j];
-                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)(ebuf + ml * 256 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                    for (int i = 0; i < 4; ++i) {
+                        const int ml = i * 16 + (lane & 15);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int slot = wn * 16 + j * 4 + (lane >> 4);      // 8-byte slot (4 bf16) in the row
+                            const f32x4 v = acc[i][j];
+                            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *(u32x2*)(ebuf + ml * 256 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                        }
+                    }
                 }
-            }
-            lds_barrier();
+                lds_barrier();
 #pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int r = ps * 16 + (tid >> 4), c = tid & 15;
-                const u32x4 v = *(const u32x4*)(ebuf + r * 256 + ((c ^ (r & 15)) << 4));
-                const int gm = row0 + r, gn = col0 + c * 8;
-                if (gm < M && gn < p.N) *(u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn) = v;
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 16 + (tid >> 4), c = tid & 15;
+                    const u32x4 v = *(const u32x4*)(ebuf + r * 256 + ((c ^ (r & 15)) << 4));
+                    const int gm = row0 + half * 64 + r, gn = col0 + c * 8;
+                    if (gm < M && gn < p.N) *(u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn) = v;
+                }
+                lds_barrier();
             }
-            lds_barrier();
         } else {
+            char* ebuf = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {                          // 64 rows x 128 fp32 = 32 KiB per pass
                 if (wm == half) {
@@ -419,7 +443,7 @@ int g_nt_wgs = 512;        // persistent grid: 2 workgroups (64 KiB LDS each) pe
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
     g_attr_done = true;
@@ -438,7 +462,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     ensure_attrs();
     NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), GEMM_LDS, stream, a);
+    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), NT_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

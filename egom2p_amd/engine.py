@@ -363,7 +363,8 @@ class Engine:
             ops.gemm_nt(dY, l.wt, dX, rows, l.in_f, l.out_f, L.EPI_BF16, lda=dY.shape[-1], ldb=l.out_f, ldc=dX.shape[-1])
         tiles = (l.out_f // 128) * (l.in_f // 128)
         steps = max(1, (rows + 63) // 64)
-        splits = max(1, min(steps, (512 + tiles - 1) // tiles, self.slab.numel() // (l.out_f * l.in_f)))
+        # one full round of workgroups (2 per CU x 256 CUs): tiles * splits <= 512, never a second, mostly empty round
+        splits = max(1, min(steps, 512 // tiles, self.slab.numel() // (l.out_f * l.in_f)))
         ops.gemm_tn(dY, X, l.g, l.out_f, l.in_f, rows, splits=splits, slab=self.slab if splits > 1 else None,
                     ldp=dY.shape[-1], ldq=X.shape[-1], ldc=l.in_f)
 
