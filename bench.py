@@ -77,8 +77,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("EGOM2P_FORCE_REDUCER") == "1":
         torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -96,7 +98,8 @@ def main():
     pool = 2                                     # distinct micro-batches per rank, cycled (inputs stay in HBM)
     mbs_cpu = [synth.make_clip_batch(cfg, mb, budgets, seed=100 + rank, sample_offset=i * mb) for i in range(pool)]
     mbs = [{k: {kk: vv.to(dev) for kk, vv in v.items()} for k, v in m.items()} for m in mbs_cpu]
-    step = TrainStep(eng, lr=args.lr, weight_decay=0.05, clip_grad=1.0, world_size=world, seed=rank)
+    step = TrainStep(eng, lr=args.lr, weight_decay=0.05, clip_grad=1.0, world_size=world, seed=rank,
+                     force_reducer=os.environ.get("EGOM2P_FORCE_REDUCER") == "1")
 
     def run_step(i):
         return step([mbs[(i * n_mb + j) % pool] for j in range(n_mb)])
@@ -157,7 +160,7 @@ def main():
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, eng, mbs_cpu[0], [m.name for m in cfg.mods], n_enc, n_dec)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -23,20 +23,22 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0):
+    def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0, force: bool = False):
         self.G = flat_grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: rehearse the path with one rank
         self.cap = int(bucket_cap_mb * 1024 * 1024 / flat_grad.element_size())
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []     # for tests / introspection
+        self.last_launched: List[Tuple[int, int]] = []
 
     # buckets arrive tail-first and contiguous: [lo, hi) then [lo', lo) ...; merge until >= cap
     def on_bucket(self, name: str, lo: int, hi: int):
-        if self.world == 1:
+        if not self.active:
             return
         if self._pending is None:
             self._pending = (lo, hi)
@@ -64,7 +66,7 @@ class GradBucketReducer:
     def finish(self):
         """Flush the tail bucket and make the compute stream wait for every outstanding all-reduce
         (host does not block with the NCCL/RCCL backend)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._pending is not None:
             self._launch(*self._pending)
@@ -74,6 +76,7 @@ class GradBucketReducer:
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works.clear()
+        self.last_launched, self.launched = self.launched, []
 
     def reduce_all(self):
         """Un-overlapped fallback: one all-reduce over the whole buffer."""

@@ -18,11 +18,11 @@ from .optim import FusedAdamW
 
 class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4, weight_decay: float = 0.05, clip_grad: Optional[float] = 1.0,
-                 process_group=None, world_size: int = 1, seed: int = 0):
+                 process_group=None, world_size: int = 1, seed: int = 0, force_reducer: bool = False):
         self.engine = engine
         self.opt = FusedAdamW(engine, lr=lr, weight_decay=weight_decay, world_size=world_size)
         self.clip = clip_grad
-        self.reducer = GradBucketReducer(engine.G, process_group) if world_size > 1 else None
+        self.reducer = GradBucketReducer(engine.G, process_group, force=force_reducer) if (world_size > 1 or force_reducer) else None
         self.rng = random.Random(seed)           # decoder modality shuffle (egom2p_model.py:312), per forward
         self.loss_sum = torch.zeros(1 + engine.n_mods, device=engine.dev)
 

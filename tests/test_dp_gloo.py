@@ -57,7 +57,7 @@ def _worker(rank, world, port, ret):
         hi -= n
     red.finish()
     assert hi == 0
-    covered = sorted(red.launched)
+    covered = sorted(red.last_launched)
     assert covered[0][0] == 0 and covered[-1][1] == G.numel()
     assert all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:]))       # every element reduced exactly once
     assert len(covered) > 1                                                   # really bucketed
@@ -84,4 +84,4 @@ def test_reducer_is_noop_single_process():
     red.on_bucket("x", 5, 10)
     red.on_bucket("y", 0, 5)
     red.finish()
-    assert red.launched == []
+    assert red.launched == [] and red.last_launched == []
