@@ -65,6 +65,7 @@ _SIGS = {
     "ego_grad_sqnorm": [vp, i64, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
     "ego_grad_scale": [vp, i64, f32, f32, vp, vp],
+    "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
 }
 
 EXPORTS = tuple(_SIGS)

@@ -589,6 +589,110 @@ class Engine:
         self._alloc_workspaces()
         self._have_fwd = False
 
+    # ------------------------------------------------------------------------------------ generation (config 4)
+    def _alloc_infer(self, B: int, Nmax: int, Mmax: int):
+        """One set of buffers (nothing is saved for a backward) for encoder-decoder passes of the ROAR / CFG
+        generation path, sized for up to Nmax encoder rows and Mmax decoder rows per sample."""
+        key = (B, Nmax, Mmax)
+        if getattr(self, "_infer_key", None) is not None and all(a >= b for a, b in zip(self._infer_key, key)):
+            return self._iw
+        D, Fp, H, dev = self.D, self.Fp, self.H, self.dev
+        R = B * max(Nmax, Mmax)
+
+        def e(*shape, dt=BF16):
+            return torch.empty(*shape, device=dev, dtype=dt)
+
+        w = dict(
+            side=dict(ids_keep=e(B, Nmax, dt=torch.int64), pad=e(B, Nmax, dt=torch.uint8), mod_mask=e(B, Nmax, dt=torch.int16),
+                      slot=e(B, Nmax, dt=I32), local=e(B, Nmax, dt=I32), tok=e(B, Nmax, dt=I32), ks=e(B, Nmax, dt=I32),
+                      ke=e(B, Nmax, dt=I32), n_valid=torch.zeros(B, device=dev, dtype=I32), seg=e(B, self.n_mods, 2, dt=I32),
+                      err=torch.zeros(1, device=dev, dtype=I32)),
+            xa=e(R, D, dt=F32), xb=e(R, D, dt=F32), emb=e(B * Nmax, D, dt=F32), ctx=e(B * Nmax, D, dt=F32),
+            ya=e(B * Mmax, D, dt=F32), yb=e(B * Mmax, D, dt=F32),
+            ln=e(R, D), qkv=e(R, 3 * D), ao=e(R, D), ab=e(R, 2 * Fp), h=e(R, Fp), q=e(B * Mmax, D), cn=e(B * Nmax, D),
+            kv=e(B * Nmax, 2 * D), st=e(2, R, dt=F32), lse=e(B, H, max(Nmax, Mmax), dt=F32),
+            zero_b=torch.zeros(B, device=dev, dtype=I32), full_m=torch.zeros(B, device=dev, dtype=I32),
+            dslot=torch.zeros(B * Mmax, device=dev, dtype=I32), dtok=torch.zeros(B * Mmax, device=dev, dtype=I32),
+        )
+        self._iw, self._infer_key = w, key
+        return w
+
+    @torch.no_grad()
+    def infer_logits(self, enc_inputs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], n_enc: int, target: str,
+                     dec_pos: torch.Tensor) -> torch.Tensor:
+        """One encoder-decoder pass of `forward_enc_dec_roar_batched` (egom2p/models/generate.py:747-766).
+
+        enc_inputs: modality -> (ids int64 [B, n], input_mask bool [B, n]); n_enc = rows kept per sample (the
+        reference takes the max unmasked count over the batch, :413-415; 0 = unconditional pass with an empty
+        context).  dec_pos: int [B, M] positions of the decoded target tokens inside `target` (their order is the
+        ROAR order; decoder self-attention is unmasked, sa_mask=None at :761).  Returns bf16 logits [B, M, V]."""
+        if self.weights_dirty:
+            self.refresh_weights()
+        cfg, D, Fp, H = self.cfg, self.D, self.Fp, self.H
+        byname = {m.name: m for m in self.mods}
+        mods = [m for m in self.mods if m.name in enc_inputs]
+        tm = byname[target]
+        B, M = dec_pos.shape
+        N = int(n_enc)
+        w = self._alloc_infer(B, max(N, 1), M)
+        side = w["side"]
+        RN, RM = B * N, B * M
+        x = None
+        if N > 0:
+            ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
+                        None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
+            x, xn = w["xa"], w["xb"]
+            ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
+                          [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
+                          x, w["emb"], RN, D)
+            Ns = side["ks"].shape[1]                    # row stride of the side buffers (allocated for Nmax)
+            for i in range(cfg.encoder_depth):
+                pre = f"encoder.{i}"
+                ops.layernorm_fwd(x[:RN], self.p[f"{pre}.norm1.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
+                self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
+                self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
+                ops.layernorm_fwd(xn[:RN], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._lin_fwd(f"{pre}.mlp.fc13", w["ln"], w["ab"], RN)
+                ops.swiglu_fwd(w["ab"], w["h"], RN, Fp)
+                self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
+            ops.layernorm_fwd(x[:RN], self.p["encoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._lin_fwd("decoder_proj_context.weight", w["ln"], w["ctx"], RN, L.EPI_BIAS_RESID, R=w["emb"],
+                          bias=self.p["decoder_proj_context.bias"])
+        # decoder rows: mask token + positional + modality embedding of the selected target positions (:481-516)
+        y, yn = w["ya"], w["yb"]
+        local = dec_pos.to(self.dev, I32).contiguous()
+        ops.embed_fwd(None, [self.pos[tm.name]], [self.p[f"encoder_embeddings.{tm.name}.mod_emb"]], self.p["mask_token"],
+                      w["dslot"], local, w["dtok"], y, None, RM, D)
+        w["full_m"].fill_(M)
+        for i in range(cfg.decoder_depth):
+            pre = f"decoder.{i}"
+            ops.layernorm_fwd(y[:RM], self.p[f"{pre}.norm1.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RM)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], w["full_m"], 1, 0, B, M, M)
+            self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RM, L.EPI_RESID, R=y)
+            if N > 0:
+                ops.layernorm_fwd(yn[:RM], self.p[f"{pre}.query_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RM)
+                ops.layernorm_fwd(w["ctx"][:RN], self.p[f"{pre}.context_norm.weight"], w["cn"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
+                self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, M, N)
+                self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RM, L.EPI_RESID, R=yn)
+            else:
+                # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the
+                # bias-free proj keeps it 0, so the cross-attention residual is the identity
+                y, yn = yn, y
+            ops.layernorm_fwd(y[:RM], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._lin_fwd(f"{pre}.mlp.fc13", w["ln"], w["ab"], RM)
+            ops.swiglu_fwd(w["ab"], w["h"], RM, Fp)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RM, L.EPI_RESID, R=y)
+            y, yn = yn, y
+        ops.layernorm_fwd(y[:RM], self.p["decoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+        l = self.lin[self.logit_key[tm.name]]
+        logits = torch.empty(RM, tm.vocab_size, device=self.dev, dtype=BF16)
+        ops.gemm_nt(w["ln"], l.wb, logits, RM, tm.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=tm.vocab_size)
+        return logits.view(B, M, tm.vocab_size)
+
     @torch.no_grad()
     def forward_logits(self, mod_dict, dec_order=None) -> Dict[str, torch.Tensor]:
         """`return_logits=True` path of EgoM2P.forward (egom2p_model.py:727-729, 546-547): logits of every

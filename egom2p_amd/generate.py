@@ -1,0 +1,181 @@
+"""ROAR + classifier-free-guidance generation over the HIP engine (BASELINE config 4).
+
+Mirrors the part of `egom2p/models/generate.py` the reference's eval scripts use
+(`eval_model_rgb2depth.py:43-96`): `build_chained_generation_schedules` (:197-322),
+`init_empty_target_modality` (:83-115), `init_full_input_modality` (:117-151), `empty_img_modality`
+(:30-37) and `GenerationSampler.generate` (:1031-1099) for token modalities with scheme 'roar', with or
+without guidance (`roar_step_batched` :768-783, `guided_roar_step_batched` :785-817).  MaskGIT,
+autoregressive text and multi-guided generation are outside the hot-path scope and raise.
+
+Per schedule step: two encoder-decoder passes on the engine (conditional / unconditional; the
+unconditional one sees an empty context on the first step), then ONE HIP kernel per step does the CFG
+mix, nucleus filtering, temperature softmax and sampling for all rows (`ego_sample_cfg_topp`).  The
+random ROAR order and the sampling uniforms come from torch's generator seeded with `seed + step`
+like the reference (:1050, :484-485); they are explicit inputs of the kernels, so a test can pin them.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------- schedules
+def linear_schedule(num_steps: int, total_tokens: int) -> np.ndarray:
+    """egom2p/utils/generation.py: tokens per step, descending, zeros trimmed."""
+    edges = np.linspace(0, total_tokens, num_steps + 1, dtype=int)
+    steps = np.sort(np.diff(edges))[::-1]
+    return np.trim_zeros(steps, "b")
+
+
+def cosine_schedule(num_steps: int, total_tokens: int) -> np.ndarray:
+    s = np.array([0.5 * (1 + math.cos(math.pi * i / num_steps)) for i in range(num_steps)])
+    toks = [round(total_tokens * d) for d in (s[:-1] - s[1:])]
+    toks.append(total_tokens - sum(toks))
+    return np.array(toks)
+
+
+def build_chained_generation_schedules(cond_domains: List[str], target_domains: List[str], tokens_per_target: List[int],
+                                       autoregression_schemes: List[str], decoding_steps: List[int],
+                                       token_decoding_schedules: List[str], temps: List[float], temp_schedules: List[str],
+                                       cfg_scales: List[float], cfg_schedules: List[str], cfg_grow_conditioning: bool = False,
+                                       modality_info: Optional[dict] = None) -> List[dict]:
+    out, cond = [], list(cond_domains)
+    for i, target in enumerate(target_domains):
+        scheme, ntoks = autoregression_schemes[i], tokens_per_target[i]
+        if scheme == "roar":
+            sched = linear_schedule(decoding_steps[i], ntoks)
+        elif scheme == "maskgit":
+            sched = cosine_schedule(decoding_steps[i], ntoks) if token_decoding_schedules[i] == "cosine" else linear_schedule(decoding_steps[i], ntoks)
+        else:
+            raise NotImplementedError(f"scheme {scheme} is outside the hot-path scope")
+        n = len(sched)
+        if temp_schedules[i] == "constant":
+            t_s = temps[i] * np.ones(decoding_steps[i])
+        elif temp_schedules[i] == "linear":
+            t_s = np.concatenate([[temps[i]], (temps[i] * (sched.sum() - sched.cumsum()) / sched.sum())[:-1]]).clip(min=1e-9)
+        else:
+            raise NotImplementedError(f"temperature schedule {temp_schedules[i]}")
+        if cfg_schedules[i] != "constant":
+            raise NotImplementedError(f"guidance schedule {cfg_schedules[i]}")
+        c_s = cfg_scales[i] * np.ones(decoding_steps[i])
+        for tok, t, c in zip(sched, t_s, c_s):
+            out.append({"target_domain": target, "scheme": scheme, "num_tokens": int(tok), "temperature": float(t),
+                        "cfg_scale": float(c), "cfg_cond_domains": list(cond)})
+        if cfg_grow_conditioning:
+            cond.append(target)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- mod_dict helpers
+def empty_img_modality(mod_dict, key):
+    mod_dict[key]["input_mask"][:] = True
+    mod_dict[key]["target_mask"][:] = False
+    return mod_dict
+
+
+def init_empty_target_modality(mod_dict, modality_info, domain, batch_size, num_tokens, device):
+    if modality_info[domain]["type"] not in ("img", "gaze", "cam", "keypoints"):
+        raise NotImplementedError("sequence modalities are outside the hot-path scope")
+    mod_dict[domain] = {"tensor": torch.zeros((batch_size, num_tokens), dtype=torch.int64, device=device),
+                        "input_mask": torch.ones((batch_size, num_tokens), dtype=torch.bool, device=device),
+                        "target_mask": torch.zeros((batch_size, num_tokens), dtype=torch.bool, device=device)}
+    return empty_img_modality(mod_dict, domain)
+
+
+def init_full_input_modality(mod_dict, modality_info, domain, device, eos_id=3):
+    if modality_info[domain]["type"] not in ("img", "gaze", "cam", "keypoints"):
+        raise NotImplementedError("sequence modalities are outside the hot-path scope")
+    d = mod_dict[domain]
+    shape = (d["tensor"].shape[0], int(np.prod(d["tensor"].shape[1:])))
+    d.setdefault("input_mask", torch.zeros(shape, dtype=torch.bool, device=device))
+    d.setdefault("target_mask", torch.ones(shape, dtype=torch.bool, device=device))
+    d.setdefault("decoder_attention_mask", torch.zeros(shape, dtype=torch.bool, device=device))
+    d["input_mask"][:] = False
+    d["target_mask"][:] = True
+    return mod_dict
+
+
+# ---------------------------------------------------------------------------------------------- sampler
+class GenerationSampler:
+    def __init__(self, model):
+        self.model = model
+        self.engine = model.engine if hasattr(model, "engine") else model
+
+    # one encoder-decoder pass (forward_enc_dec_roar_batched, generate.py:747-766) ---------------------
+    def _logits(self, mod_dict, target_mod, mod_pos):
+        eng = self.engine
+        enc, n_enc = {}, 0
+        for m in eng.mods:
+            if m.name not in mod_dict:
+                continue
+            d = mod_dict[m.name]
+            B = d["tensor"].shape[0]
+            ids = d["tensor"].reshape(B, -1).to(eng.dev, torch.int64)
+            mask = d["input_mask"].reshape(B, -1).to(eng.dev, torch.bool)
+            enc[m.name] = (ids, mask)
+        # rows kept by forward_mask_encoder_generation = max unmasked count over the batch (:413-415)
+        n_enc = int(torch.stack([(~v[1]).sum(1) for v in enc.values()]).sum(0).max().item()) if enc else 0
+        return eng.infer_logits(enc, n_enc, target_mod, mod_pos)
+
+    def roar_order(self, target_mask: torch.Tensor, num_select: int, seed: Optional[int]) -> torch.Tensor:
+        """Positions decoded in this step (forward_mask_decoder_roar, :481-516): unmasked targets in a random
+        order shared by the batch, the first `num_select` of them."""
+        dev = target_mask.device
+        if seed is not None:
+            torch.manual_seed(seed)
+        n_dec = min(int(num_select), int((~target_mask[0]).sum().item()))
+        noise = torch.rand(target_mask.shape[1], device=dev).unsqueeze(0) * 1e-6
+        ids_shuffle = torch.argsort(target_mask.float() + noise, dim=1)
+        return ids_shuffle[:, :n_dec]
+
+    def roar_step(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
+                  seed=None, mod_pos: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
+                  return_logits: bool = False, forced_samples: Optional[torch.Tensor] = None):
+        if top_k and top_k > 0:
+            raise NotImplementedError("top-k filtering is outside the hot-path scope (config 4 uses top-p)")
+        eng = self.engine
+        d = mod_dict[target_mod]
+        if mod_pos is None:
+            mod_pos = self.roar_order(d["target_mask"].to(eng.dev), num_select, seed)
+        mod_pos = mod_pos.to(eng.dev)
+        logits_cond = self._logits(mod_dict, target_mod, mod_pos)
+        logits_uncond = None
+        if guidance_scale != 1.0 and len(conditioning) > 0:
+            uncond = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in mod_dict.items()}
+            for mod in conditioning:
+                uncond = empty_img_modality(uncond, mod)
+            logits_uncond = self._logits(uncond, target_mod, mod_pos)
+        B, M, V = logits_cond.shape
+        if uniforms is None:
+            uniforms = torch.rand(B * M, device=eng.dev)
+        samples = torch.empty(B * M, device=eng.dev, dtype=torch.int32)
+        ops.sample_cfg_topp(logits_cond.view(B * M, V), None if logits_uncond is None else logits_uncond.view(B * M, V), V,
+                            float(guidance_scale), float(top_p), float(temperature), uniforms, samples, ld=V)
+        samples = samples.view(B, M).to(torch.int64)
+        drawn = samples
+        if forced_samples is not None:             # teacher forcing for parity tests: scatter the given tokens instead
+            samples = forced_samples.to(eng.dev, torch.int64).view(B, M)
+        d["tensor"] = torch.scatter(d["tensor"].reshape(B, -1).to(eng.dev), -1, mod_pos, samples)
+        d["input_mask"] = torch.scatter(d["input_mask"].to(eng.dev), -1, mod_pos, torch.zeros_like(samples, dtype=torch.bool))
+        d["target_mask"] = torch.scatter(d["target_mask"].to(eng.dev), -1, mod_pos, torch.ones_like(samples, dtype=torch.bool))
+        if return_logits:
+            return mod_dict, dict(logits_cond=logits_cond, logits_uncond=logits_uncond, mod_pos=mod_pos, samples=drawn)
+        return mod_dict
+
+    @torch.no_grad()
+    def generate(self, mod_dict, schedule, top_k=0.0, top_p=0.0, text_tokenizer=None, verbose=False, seed=None):
+        mod_dict = copy.deepcopy(mod_dict)
+        for step, info in enumerate(schedule):
+            target = info["target_domain"]
+            if info["scheme"].lower() != "roar":
+                raise NotImplementedError(f"scheme {info['scheme']} is outside the hot-path scope")
+            mod_dict = self.roar_step(mod_dict, target, info["num_tokens"], info["temperature"], top_k, top_p,
+                                      conditioning=info.get("cfg_cond_domains", []), guidance_scale=info.get("cfg_scale", 1.0),
+                                      seed=None if seed is None else seed + step)
+        return mod_dict

@@ -174,3 +174,10 @@ def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D):
 def loss_perm(seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base):
     check(L.load().ego_loss_perm(_p(seg), _p(canon), _p(slot), _p(tok), B, M, n_mods, _p(perm), _p(tgt_perm), _p(ranges),
                                  _p(base), _stream()), "ego_loss_perm")
+
+
+def sample_cfg_topp(cond, uncond, V, cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob=None, ld=None):
+    rows = out_tokens.numel()
+    ld = cond.stride(-2) if ld is None else ld
+    check(L.load().ego_sample_cfg_topp(_p(cond), _p(uncond), ld, V, cfg_scale, top_p, temperature, _p(uniforms), _p(out_tokens),
+                                       _p(out_prob), rows, _stream()), "ego_sample_cfg_topp")

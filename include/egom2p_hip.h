@@ -141,6 +141,17 @@ int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* rang
 /* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality. */
 int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream);
 
+/* ---- generation (config 4) ------------------------------------------------------------------- */
+
+/* Per decoded row: logits = uncond + (cond - uncond) * cfg_scale (uncond NULL: logits = cond); nucleus
+ * filter top_p (<= 0: off) on softmax(logits); sample from softmax(kept / temperature) with the caller's
+ * uniform number uniforms[row] (temperature <= 1e-10: arg-max).  Replaces guided_roar_step_batched's CFG mix,
+ * top_k_top_p_filtering, softmax and torch.multinomial (egom2p/models/generate.py:332-371, 805-808).
+ * cond/uncond: bf16 [rows, ld >= V]; out_prob (optional): probability of the sampled token. */
+int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, float cfg_scale, float top_p,
+                        float temperature, const float* uniforms, int* out_tokens, float* out_prob, int rows,
+                        hipStream_t stream);
+
 /* ---- parameters / optimiser ------------------------------------------------------------------ */
 
 /* fp32 master W[rows, cols] -> bf16 W (zero-padded to rows_dst rows) and/or bf16 W^T [cols, rows_dst]. */

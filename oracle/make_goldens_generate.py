@@ -1,0 +1,111 @@
+"""ORACLE tooling - golden vectors for the ROAR + CFG generation path (BASELINE config 4) from the REAL
+reference `GenerationSampler` (egom2p/models/generate.py), run in the build container only.
+
+The reference's files are loaded by path (see make_goldens.py); the conditioning clip is the reference's own
+data file example_data/rgb2cam_egoexo.npz (real Cosmos token ids, stored in the fixture as data); weights
+come from the counter-based generator.  Per schedule step the fixture holds the ROAR positions, per-row
+statistics of the conditional / unconditional logits, and the tokens the reference sampled (teacher forcing
+for the next step).
+
+    python oracle/make_goldens_generate.py
+"""
+from __future__ import annotations
+
+import copy
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from egom2p_amd import synth                      # noqa: E402
+from egom2p_amd.config import MODEL_CFGS          # noqa: E402
+import make_goldens as MG                         # noqa: E402
+
+
+def main():
+    enc, dec, model = MG.load_reference()
+    REF = MG.REF
+
+    def _load(modname, relpath):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    gen_utils = _load("egom2p.utils.generation", "egom2p/utils/generation.py")
+    sys.modules.setdefault("egom2p.utils.tokenizer", type(sys)("egom2p.utils.tokenizer"))
+    tt = _load("egom2p.utils.tokenizer.text_tokenizer", "egom2p/utils/tokenizer/text_tokenizer.py")
+    sys.modules["egom2p.utils"].get_sentinel_to_id_mapping = tt.get_sentinel_to_id_mapping
+    sys.modules["egom2p.utils"].merge_span_masking = tt.merge_span_masking
+    G = _load("egom2p.models.generate", "egom2p/models/generate.py")
+
+    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    seed = 21
+    torch.set_num_threads(8)
+    torch.set_grad_enabled(False)
+    net = MG.build_reference_model(cfg, enc, dec, model)
+    net.load_state_dict(synth.build_state_dict(cfg, seed), strict=True)
+    net.eval()
+    sampler = G.GenerationSampler(net)
+    info = net.modality_info
+
+    rgb = np.load(os.path.join(REF, "example_data", "rgb2cam_egoexo.npz"))
+    key = [k for k in rgb.files][0]
+    ids = np.asarray(rgb[key]).astype(np.int64).reshape(1, 5, 32, 32)
+    sample = {"tok_rgb": {"tensor": torch.from_numpy(ids), "input_mask": torch.zeros(1, 5120, dtype=torch.bool),
+                          "target_mask": torch.ones(1, 5120, dtype=torch.bool)}}
+    sample = G.init_empty_target_modality(sample, info, "tok_depth", 1, 5120, "cpu")
+    sample = G.init_full_input_modality(sample, info, "tok_rgb", "cpu")
+    schedule = G.build_chained_generation_schedules(
+        cond_domains=["tok_rgb"], target_domains=["tok_depth"], tokens_per_target=[5120], autoregression_schemes=["roar"],
+        decoding_steps=[3], token_decoding_schedules=["linear"], temps=[0.01], temp_schedules=["constant"],
+        cfg_scales=[2.0], cfg_schedules=["constant"], cfg_grow_conditioning=True)
+    top_p, top_k, gseed = 0.8, 0.0, 0
+
+    gold = {"rgb_ids": ids.astype(np.int32), "n_steps": np.array(len(schedule)),
+            "meta": np.array(repr(dict(cfg="ego_gen_384_2e_2d", seed=seed, top_p=top_p, gen_seed=gseed)))}
+    mod_dict = copy.deepcopy(sample)
+    for step, sinfo in enumerate(schedule):
+        target, num_select, temp, cfg_scale = sinfo["target_domain"], sinfo["num_tokens"], sinfo["temperature"], sinfo["cfg_scale"]
+        cond_doms = sinfo["cfg_cond_domains"]
+        seed_i = gseed + step
+        logits_cond, _ = sampler.forward_enc_dec_roar_batched(mod_dict, target, num_select, seed=seed_i)
+        unc = copy.deepcopy(mod_dict)
+        for m in cond_doms:
+            unc = G.empty_img_modality(unc, m)
+        logits_uncond, mod_pos = sampler.forward_enc_dec_roar_batched(unc, target, num_select, seed=seed_i)
+        mixed = logits_uncond + (logits_cond - logits_uncond) * cfg_scale
+        torch.manual_seed(1000 + step)
+        samples, probs = sampler.sample_tokens_batched(mixed.clone(), temp, top_k=top_k, top_p=top_p)
+        for nm, lg in (("cond", logits_cond), ("uncond", logits_uncond), ("mixed", mixed)):
+            lg2 = lg[0].float()
+            gold[f"s{step}.{nm}.head"] = lg2[:6, :48].numpy().copy()
+            gold[f"s{step}.{nm}.argmax"] = lg2.argmax(-1).numpy().astype(np.int32)
+            gold[f"s{step}.{nm}.max"] = lg2.max(-1).values.numpy()
+            gold[f"s{step}.{nm}.lse"] = torch.logsumexp(lg2, -1).numpy()
+            gold[f"s{step}.{nm}.rownorm"] = lg2.norm(dim=-1).numpy()
+        gold[f"s{step}.mod_pos"] = mod_pos.numpy().astype(np.int32)
+        gold[f"s{step}.samples"] = samples.numpy().astype(np.int32)
+        gold[f"s{step}.cfg"] = np.array([num_select, temp, cfg_scale])
+        gold[f"s{step}.n_enc"] = np.array([int((~mod_dict[m]["input_mask"]).sum()) for m in ("tok_rgb", "tok_depth")])
+        mod_dict[target]["tensor"] = torch.scatter(mod_dict[target]["tensor"], -1, mod_pos, samples)
+        mod_dict[target]["input_mask"] = torch.scatter(mod_dict[target]["input_mask"], -1, mod_pos, torch.zeros_like(samples, dtype=torch.bool))
+        mod_dict[target]["target_mask"] = torch.scatter(mod_dict[target]["target_mask"], -1, mod_pos, torch.ones_like(samples, dtype=torch.bool))
+        print(f"[goldens] step {step}: select {num_select}, enc tokens cond {gold[f's{step}.n_enc'].sum()}", flush=True)
+    gold["final_tokens"] = mod_dict["tok_depth"]["tensor"].numpy().astype(np.int32)
+    # schedule check values
+    gold["schedule_tokens"] = np.array([s["num_tokens"] for s in schedule])
+    path = os.path.join(ROOT, "tests", "golden", "gen_rgb2depth.npz")
+    np.savez_compressed(path, **gold)
+    print(f"[goldens] -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()

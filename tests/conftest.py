@@ -23,7 +23,8 @@ def load_golden(case):
         pytest.skip(f"golden fixture {case}.npz not present")
     g = np.load(path, allow_pickle=False)
     meta = ast.literal_eval(str(g["meta"]))
-    meta["budgets"] = ast.literal_eval(meta["budgets"])
+    if "budgets" in meta:
+        meta["budgets"] = ast.literal_eval(meta["budgets"])
     return g, meta
 
 

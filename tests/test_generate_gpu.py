@@ -1,0 +1,138 @@
+"""BASELINE config 4 (rgb -> depth ROAR + CFG generation) on the GPU against fixtures made
+by the REAL reference `GenerationSampler` (tests/golden/gen_rgb2depth.npz, oracle/make_goldens_generate.py)."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, rel_l2  # noqa: E402
+from egom2p_amd import ops, synth  # noqa: E402
+from egom2p_amd.config import MODEL_CFGS  # noqa: E402
+from egom2p_amd.engine import Engine  # noqa: E402
+from egom2p_amd.generate import (GenerationSampler, build_chained_generation_schedules, init_empty_target_modality,  # noqa: E402
+                                 init_full_input_modality)
+from egom2p_amd.model import MODALITY_INFO  # noqa: E402
+
+DEV = "cuda"
+
+
+def _ref_filter(logits, top_p):
+    """the reference's top_k_top_p_filtering (generate.py:348-357) restated with torch ops, as the checker"""
+    sl, si = torch.sort(logits, dim=1, descending=True)
+    cp = torch.cumsum(torch.softmax(sl, -1), -1)
+    rm = cp > top_p
+    rm[:, 1:] = rm[:, :-1].clone()
+    rm[:, 0] = False
+    restore = torch.argsort(si, -1)
+    return torch.gather(rm, -1, restore)
+
+
+def test_sampler_kernel_nucleus_and_distribution():
+    torch.manual_seed(0)
+    rows, V = 64, 64000
+    cond = (torch.randn(rows, V, device=DEV) * 3).bfloat16()
+    unc = (torch.randn(rows, V, device=DEV) * 3).bfloat16()
+    s = 2.0
+    mixed = unc.float() + (cond.float() - unc.float()) * s
+    removed = _ref_filter(mixed.clone(), 0.8)
+    # (1) tiny temperature: the sample is the arg-max of the mixed logits and lies in the reference's nucleus
+    u = torch.rand(rows, device=DEV)
+    tok = torch.empty(rows, device=DEV, dtype=torch.int32)
+    prob = torch.empty(rows, device=DEV)
+    ops.sample_cfg_topp(cond, unc, V, s, 0.8, 1e-4, u, tok, prob, ld=V)
+    assert torch.equal(tok.long(), mixed.argmax(-1))
+    # (2) temperature 1: every sample is inside the nucleus; the kernel's kept set equals the reference's
+    draws = 200
+    toks = torch.empty(draws, rows, device=DEV, dtype=torch.int32)
+    for i in range(draws):
+        ops.sample_cfg_topp(cond, unc, V, s, 0.8, 1.0, torch.rand(rows, device=DEV), toks[i], None, ld=V)
+    # tokens whose logit ties with the smallest kept logit are kept or dropped together by the kernel (the
+    # reference's sort cuts such ties arbitrarily): every sample's logit must be >= the reference's cut value
+    theta = mixed.masked_fill(removed, float("inf")).min(-1).values                  # smallest kept logit per row
+    drawn_logit = mixed.gather(1, toks.long().t())
+    assert (drawn_logit >= theta[:, None]).all()
+    strictly_inside = ~removed.gather(1, toks.long().t())
+    assert strictly_inside.float().mean().item() > 0.999
+    # (3) distribution: on a small vocabulary the empirical frequencies follow softmax(kept / T)
+    V2 = 256
+    lg = (torch.randn(1, V2, device=DEV) * 2).bfloat16()
+    n = 20000
+    many = lg.expand(n, V2).contiguous()
+    out = torch.empty(n, device=DEV, dtype=torch.int32)
+    ops.sample_cfg_topp(many, None, V2, 1.0, 0.9, 0.7, torch.rand(n, device=DEV), out, None, ld=V2)
+    rem = _ref_filter(lg.float().clone(), 0.9)[0]
+    p = torch.softmax(lg.float()[0].masked_fill(rem, float("-inf")) / 0.7, -1)
+    freq = torch.bincount(out.long(), minlength=V2).float() / n
+    assert (freq[rem] == 0).all()
+    assert (freq - p).abs().max().item() < 0.015
+    # (4) temperature 0 branch and no-guidance branch
+    ops.sample_cfg_topp(cond, None, V, 1.0, 0.0, 0.0, u, tok, prob, ld=V)
+    assert torch.equal(tok.long(), cond.float().argmax(-1)) and (prob == 1).all()
+
+
+def test_schedule_matches_reference():
+    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+                                             [2.0], ["constant"], cfg_grow_conditioning=True)
+    g, _ = load_golden("gen_rgb2depth")
+    assert [s["num_tokens"] for s in sch] == list(g["schedule_tokens"])
+    assert all(s["cfg_cond_domains"] == ["tok_rgb"] and s["cfg_scale"] == 2.0 and s["temperature"] == 0.01 for s in sch)
+
+
+def test_roar_cfg_generation_matches_reference():
+    g, meta = load_golden("gen_rgb2depth")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=64, n_dec=64)
+    eng.load_state_dict(synth.build_state_dict(cfg, meta["seed"]))
+    sampler = GenerationSampler(eng)
+    sample = {"tok_rgb": {"tensor": torch.from_numpy(g["rgb_ids"].astype(np.int64)).to(DEV)}}
+    sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 1, 5120, DEV)
+    sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+    md = sample
+    agree_total, n_total = 0, 0
+    for step in range(int(g["n_steps"])):
+        num_select, temp, cfg_scale = g[f"s{step}.cfg"]
+        mod_pos = torch.from_numpy(g[f"s{step}.mod_pos"].astype(np.int64)).to(DEV)
+        forced = torch.from_numpy(g[f"s{step}.samples"].astype(np.int64)).to(DEV)
+        md, info = sampler.roar_step(md, "tok_depth", int(num_select), float(temp), 0.0, meta["top_p"], conditioning=["tok_rgb"],
+                                     guidance_scale=float(cfg_scale), mod_pos=mod_pos, return_logits=True, forced_samples=forced)
+        for nm, lg in (("cond", info["logits_cond"]), ("uncond", info["logits_uncond"])):
+            lg = lg[0].float()
+            assert rel_l2(lg[:6, :48].cpu().numpy(), g[f"s{step}.{nm}.head"]) < 3e-2, (step, nm)
+            assert rel_l2(lg.norm(dim=-1).cpu().numpy(), g[f"s{step}.{nm}.rownorm"]) < 1e-2, (step, nm)
+            assert np.abs(torch.logsumexp(lg, -1).cpu().numpy() - g[f"s{step}.{nm}.lse"]).max() < 5e-2, (step, nm)
+            am = (lg.argmax(-1).cpu().numpy() == g[f"s{step}.{nm}.argmax"]).mean()
+            assert am > 0.9, (step, nm, am)
+        # the sampler (temperature 0.01 -> nearly greedy on the CFG-mixed logits) agrees with the reference's draws
+        mine = info["samples"][0].cpu().numpy()
+        agree_total += (mine == g[f"s{step}.samples"][0]).sum()
+        n_total += mine.size
+        # where it differs, our token's mixed logit is within bf16 noise of the reference token's
+        mixed = info["logits_uncond"][0].float() + (info["logits_cond"][0].float() - info["logits_uncond"][0].float()) * float(cfg_scale)
+        ref_tok = torch.from_numpy(g[f"s{step}.samples"][0].astype(np.int64)).to(DEV)
+        gap = (mixed.gather(1, torch.from_numpy(mine.astype(np.int64)).to(DEV)[:, None]) - mixed.gather(1, ref_tok[:, None])).abs()
+        assert gap.max().item() < 0.35, (step, gap.max().item())
+    # random-init weights give nearly flat logits: bf16 noise flips near-ties, the gap bound above is the real bar
+    assert agree_total / n_total > 0.7, agree_total / n_total
+    assert np.array_equal(md["tok_depth"]["tensor"].cpu().numpy().astype(np.int32), g["final_tokens"])   # teacher-forced state
+    assert (~md["tok_depth"]["input_mask"]).all() and md["tok_depth"]["target_mask"].all()
+
+
+def test_generate_end_to_end_runs():
+    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=2, n_enc=64, n_dec=64)
+    eng.init_random(3)
+    sampler = GenerationSampler(eng)
+    ids = synth.randint("gen.rgb", (2, 5, 32, 32), 64000, seed=5).to(DEV)
+    sample = {"tok_rgb": {"tensor": ids}}
+    sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 2, 5120, DEV)
+    sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+                                             [2.0], ["constant"], cfg_grow_conditioning=True)
+    out = sampler.generate(sample, sch, top_p=0.8, top_k=0.0, seed=0)
+    t = out["tok_depth"]["tensor"]
+    assert t.shape == (2, 5120) and int(t.min()) >= 0 and int(t.max()) < 64000
+    assert out["tok_depth"]["target_mask"].all() and not out["tok_depth"]["input_mask"].any()
+    assert sample["tok_depth"]["input_mask"].all()            # the caller's dict is untouched (deepcopy, :1046)
