@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="egom2p_base_12e_12d_swiglu_nobias")
     ap.add_argument("--clips-per-gpu", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)

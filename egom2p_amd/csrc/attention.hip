@@ -168,37 +168,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int s = 0; s < 4; ++s)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
         }
+        // online softmax in the raw-score domain: p = exp2(s * sc - m * sc) is ONE fma + one v_exp per element
+        // (this kernel is VALU-bound at head_dim 64); `m` tracks the running max of the raw scores (sc >= 0).
         const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
         float mx = NEG_BIG;
+        if (full) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = st[kb][r] * sc;
-                if (!full) {
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
-                    v = (kidx >= ks && kidx < ke) ? v : NEG_BIG;
+                    const float v = (kidx >= ks && kidx < ke) ? st[kb][r] : NEG_BIG;
+                    st[kb][r] = v;
+                    mx = fmaxf(mx, v);
                 }
-                st[kb][r] = v;
-                mx = fmaxf(mx, v);
-            }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        // the running max of most rows stops moving after the first tiles: skip the 32-register O rescale then
+        if (__any(mnew > m)) {
+            const float alpha = __builtin_amdgcn_exp2f((m - mnew) * sc);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+        }
         m = mnew;
+        const float msc = mnew * sc;
         float rs = 0.f;
+        if (full) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(st[kb][r] - mnew);
-                if (!full) pv = (st[kb][r] <= NEG_BIG) ? 0.f : pv;
-                rs += pv;
-                st[kb][r] = pv;
-            }
-        l = l * alpha + rs;
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -msc));
+                    rs += pv;
+                    st[kb][r] = pv;
+                }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = (st[kb][r] <= NEG_BIG) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -msc));
+                    rs += pv;
+                    st[kb][r] = pv;
+                }
+        }
+        l += rs;
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
             const bf16x8 pf = pack8(st[sp >> 1], sp & 1);
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     if (q0 + ql < p.Nq) {
         store_rows_bf16(p.O + (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64, ot, inv, hh);
-        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = m + __builtin_amdgcn_logf(lt);  // v_log_f32 = log2
+        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = m * sc + __builtin_amdgcn_logf(lt);  // v_log_f32 = log2
     }
 }
 
@@ -253,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     float sc = p.scale * LOG2E, gsc = p.scale;
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
     const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
+    const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
     int* rng = (int*)(smem + 4 * TILE_BYTES);
     if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
     __syncthreads();
@@ -270,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     }
     const float lse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];
     const float delta = p.DELTA[((long)b * p.H + h) * p.Nq + qrow];
+    const float dgs = delta * gsc;
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
@@ -318,15 +341,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                 dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp[kb], 0, 0, 0);
             }
         }
+        // dS^T = P o (dP^T - delta) * scale.  Interior tiles (every row of the wave sees all 64 keys) skip the
+        // interval compares: at head_dim 64 these kernels are VALU-bound, not MFMA-bound.
+        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        if (full) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
-                const bool ok = (kidx >= ks && kidx < ke);
-                const float pv = ok ? __builtin_amdgcn_exp2f(st[kb][r] * sc - lse2) : 0.f;
-                st[kb][r] = pv * (dp[kb][r] - delta) * gsc;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -lse2));
+                    st[kb][r] = pv * __builtin_fmaf(dp[kb][r], gsc, -dgs);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
+                    const bool ok = (kidx >= ks && kidx < ke);
+                    const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -lse2)) : 0.f;
+                    st[kb][r] = pv * __builtin_fmaf(dp[kb][r], gsc, -dgs);
+                }
+        }
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
             const bf16x8 dsf = pack8(st[sp >> 1], sp & 1);
@@ -387,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         if (tid < 64) {
             const int row = qt * 64 + tid;
             if (row < p.Nq) {
-                a_lse = LSEb[row]; a_del = DELb[row];
+                a_lse = LSEb[row]; a_del = DELb[row] * p.scale;      // delta * scale: dS = P * fma(dP, scale, -delta*scale)
                 a_ks = KSb[row * p.r_rs]; a_ke = min(KEb[row * p.r_rs], p.Nk);
                 if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
             } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }
@@ -426,6 +462,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 
         // does any row of this q tile look at this wave's 32 keys?
         int t_ks = ai[lane], t_ke = ai[64 + lane];
+        // (flat rows carry ks = -1, rows beyond Nq carry ks = INT_MAX: both force the general path)
+        const bool tile_full = wave_min_i((t_ks >= 0 && t_ks <= kw0 && t_ke >= kw0 + 32) ? 1 : 0) != 0;
         t_ks = (t_ks < 0) ? 0 : t_ks;
         const int lo = wave_min_i(t_ks), hi = wave_max_i(t_ke);
         if (hi > kw0 && lo < kw0 + 32) {
@@ -440,6 +478,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gt, qb, s, lane), vf[s], dp, 0, 0, 0);
                 }
                 f32x16 pv, ds;
+                if (tile_full) {
+                    // every row of this q tile sees all 32 keys of this wave: no interval compares
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int qb0 = qb * 32 + 8 * g + 4 * hh;           // 4 consecutive q rows
+                        const f32x4 lse4 = *(const f32x4*)(af + qb0);
+                        const f32x4 del4 = *(const f32x4*)(af + 64 + qb0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c_sc, -lse4[e]));
+                            pv[r] = pe;
+                            ds[r] = pe * __builtin_fmaf(dp[r], p.scale, -del4[e]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int qb0 = qb * 32 + 8 * g + 4 * hh;           // 4 consecutive q rows
@@ -456,8 +510,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                         const float x = flat ? 0.f : st[r] * c_sc;
                         const float pe = ok ? __builtin_amdgcn_exp2f(x - lse4[e]) : 0.f;
                         pv[r] = pe;
-                        ds[r] = flat ? 0.f : pe * (dp[r] - del4[e]) * p.scale;
+                        ds[r] = flat ? 0.f : pe * __builtin_fmaf(dp[r], p.scale, -del4[e]);
                     }
+                }
                 }
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
                     const int r = ps * 16 + (tid >> 4), c = tid & 15;
                     const u32x4 v = *(const u32x4*)(ebuf + r * 256 + ((c ^ (r & 15)) << 4));
                     const int gm = row0 + half * 64 + r, gn = col0 + c * 8;
-                    if (gm < M && gn < p.N) *(u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn) = v;
+                    if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
                 }
                 lds_barrier();
             }
@@ -228,6 +228,209 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         }
         if (!more) break;
         tile = next_tile;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel, 256x256 tile, 8 waves, staggered half-phases (for the large GEMMs).
+//
+// Waves 0-3 (group 0, output rows 0-127) and 4-7 (group 1, rows 128-255) share the four SIMDs pairwise
+// (wave i and i+4 sit on one SIMD).  Each K-tile (64 deep) is 4 phases, one 64x32 quadrant of the wave's
+// 128x64 output per phase: a LOAD segment (ds_read_b128 of the fragments the quadrant needs, plus this
+// wave's share of the LDS-DMA for the NEXT K-tile) and a COMPUTE segment (16 MFMAs), each closed by a
+// workgroup barrier.  Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA
+// segment while its partner reads LDS / issues DMA: the matrix pipe is fed in every half-phase slot.
+//   slot 2q   : G0 LOAD(q)      G1 COMPUTE(q-1)
+//   slot 2q+1 : G0 COMPUTE(q)   G1 LOAD(q)
+// Hazards (two 64-KiB stages, DMA one K-tile ahead):
+//   RAW  every wave drains its own DMA (vmcnt(0)) before the barrier that closes slot 7; the first read
+//        of the new tile (G0, slot 0) is behind that barrier.
+//   WAR  the DMA for tile t+1 targets the stage last read in tile t-1; G1's last reads of it (slot 7)
+//        are consumed at the head of slot 0 of tile t, so G0 issues DMA only from LOAD(1) on (slot 2),
+//        G1 from its LOAD(0) (slot 1): both behind a barrier that follows those reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int T2_BYTES = 256 * 128;            // operand tile: 256 rows x 64 bf16
+constexpr int S2_BYTES = 2 * T2_BYTES;         // stage = A + B = 64 KiB
+constexpr int NT2_LDS = 2 * S2_BYTES;          // 128 KiB: one workgroup per CU
+
+__device__ __forceinline__ void bar_pinned() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;              // grp = row half (and stagger group), wc = 64-col strip
+
+    int M = p.M;
+    long moff = 0;
+    if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
+    if (M <= 0) return;
+    const int tiles_n = (p.N + 255) / 256;
+    // M may come from the device (row range of one modality): spread the tiles that really exist over the XCDs,
+    // the surplus workgroups of the launch leave at once (otherwise whole XCDs would own only empty tiles)
+    const int ntiles = ((M + 255) / 256) * tiles_n;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int row0 = (t / tiles_n) * 256, col0 = (t % tiles_n) * 256;
+    const int nt = p.K / BK;
+
+    // LDS-DMA sources: wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 8;
+        a_src[j] = p.A + (moff + min(row0 + r, M - 1)) * p.lda + c;
+        b_src[j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + c;
+    }
+    auto dma = [&](int s, int k0, int j) {
+        glds16(a_src[j] + k0, smem + s * S2_BYTES + (wave * 4 + j) * 1024);
+        glds16(b_src[j] + k0, smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024);
+    };
+    // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
+    // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    const int a_base = grp * 128 * 128, b_base = T2_BYTES + wc * 64 * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], bq[2][2];
+
+    // prologue: K-tile 0 by all waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma(0, 0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar_pinned();
+    if (grp == 1) bar_pinned();                              // stagger: group 1 runs one barrier behind
+
+#define LOAD_A(QM)                                                                                         \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        af[mi][ks] = *(const bf16x8*)(st + a_base + ((QM) * 4 + mi) * 2048 + foff[ks]);
+#define LOAD_B(QN)                                                                                         \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        bq[ni][ks] = *(const bf16x8*)(st + b_base + ((QN) * 2 + ni) * 2048 + foff[ks]);
+#define COMPUTE(QM, QN)                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)      \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                   \
+            acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+                bq[ni][ks], af[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                       \
+    __builtin_amdgcn_s_setprio(0);
+
+    for (int kt = 0; kt < nt; ++kt) {
+        const char* st = smem + (kt & 1) * S2_BYTES;
+        const int sn = (kt & 1) ^ 1, kn = (kt + 1) * BK;
+        const bool more = kt + 1 < nt;
+        // ---- phase 0: quadrant (0,0)
+        LOAD_A(0) LOAD_B(0)
+        if (more && grp == 1) { dma(sn, kn, 0); dma(sn, kn, 1); dma(sn, kn, 2); }
+        bar_pinned();
+        COMPUTE(0, 0)
+        bar_pinned();
+        // ---- phase 1: quadrant (0,1)
+        LOAD_B(1)
+        if (more) { if (grp == 1) { dma(sn, kn, 3); } else { dma(sn, kn, 0); dma(sn, kn, 1); dma(sn, kn, 2); } }
+        bar_pinned();
+        COMPUTE(0, 1)
+        bar_pinned();
+        // ---- phase 2: quadrant (1,1)
+        LOAD_A(1)
+        if (more && grp == 0) { dma(sn, kn, 3); }
+        bar_pinned();
+        COMPUTE(1, 1)
+        bar_pinned();
+        // ---- phase 3: quadrant (1,0)
+        LOAD_B(0)
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1: its DMA landed before slot 7 closes
+        bar_pinned();
+        COMPUTE(1, 0)
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0: same, end of its COMPUTE(3) (slot 7)
+        bar_pinned();
+    }
+#undef LOAD_A
+#undef LOAD_B
+#undef COMPUTE
+    if (grp == 0) bar_pinned();                              // match group 1's extra barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // epilogue through LDS (all 128 KiB are free now): whole-row coalesced stores
+    if (p.epi == EGO_EPI_BF16) {
+        // image [256 rows][512 B]; 16-byte chunk c of row r at chunk c ^ (r & 15)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ml = grp * 128 + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
+                const f32x4 v = acc[i][j];
+                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)(smem + ml * 512 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+            }
+        }
+        lds_barrier();
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int r = ps * 16 + (tid >> 5), c = tid & 31;
+            const u32x4 v = *(const u32x4*)(smem + r * 512 + ((c ^ (r & 15)) << 4));
+            const int gm = row0 + r, gn = col0 + c * 8;
+            if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                               // 128 rows x 256 fp32 = 128 KiB per pass
+            // residual operand first: 16 independent 16-byte loads per lane in flight under the LDS transpose
+            const bool has_r = (p.epi == EGO_EPI_RESID || p.epi == EGO_EPI_BIAS_RESID);
+            f32x4 rr[16];
+            if (has_r) {
+#pragma unroll
+                for (int ps = 0; ps < 16; ++ps) {
+                    const int gm = row0 + half * 128 + ps * 8 + (tid >> 6), gn = col0 + (tid & 63) * 4;
+                    rr[ps] = (gm < M && gn < p.N) ? __builtin_nontemporal_load((const f32x4*)(p.R + (moff + gm) * p.ldr + gn))
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.epi == EGO_EPI_BIAS_RESID) {
+                const int gn = col0 + (tid & 63) * 4;
+                if (gn < p.N) { const f32x4 b = *(const f32x4*)(p.bias + gn); bb = f32x4{round_bf16(b[0]), round_bf16(b[1]), round_bf16(b[2]), round_bf16(b[3])}; }
+            }
+            if (grp == half) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ml = i * 16 + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = wc * 16 + j * 4 + (lane >> 4);         // 16-byte chunk (4 fp32), 64 per row
+                        *(f32x4*)(smem + ml * 1024 + ((c ^ (ml & 15)) << 4)) = acc[i][j];
+                    }
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                const int r = ps * 8 + (tid >> 6), c = tid & 63;
+                f32x4 v = *(const f32x4*)(smem + r * 1024 + ((c ^ (r & 15)) << 4));
+                const int gm = row0 + half * 128 + r, gn = col0 + c * 4;
+                if (gm < M && gn < p.N) {
+                    if (has_r) {
+                        const f32x4 q = rr[ps];
+                        v = f32x4{q[0] + round_bf16(v[0] + bb[0]), q[1] + round_bf16(v[1] + bb[1]),
+                                  q[2] + round_bf16(v[2] + bb[2]), q[3] + round_bf16(v[3] + bb[3])};
+                    }
+                    *(f32x4*)((float*)p.C + (moff + gm) * p.ldc + gn) = v;
+                }
+            }
+            lds_barrier();
+        }
     }
 }
 
@@ -440,12 +643,15 @@ __global__ void tn_reduce_kernel(const float* slab, float* C0, float* C1, long l
 }
 
 int g_nt_wgs = 512;        // persistent grid: 2 workgroups (64 KiB LDS each) per CU x 256 CUs
+int g_nt256 = 1;           // use the 256x256 staggered kernel for large shapes (EGO_GEMM_NT256=0 disables)
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
     if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
+    if (const char* e = getenv("EGO_GEMM_NT256")) g_nt256 = atoi(e);
     g_attr_done = true;
 }
 
@@ -461,6 +667,17 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
+    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    // the 256x256 kernel runs one workgroup per CU: take it when the grid fills whole rounds of 256 reasonably well
+    // measured on MI355X (tools/gemm_bench.py): the 256x256 kernel wins whenever the grid fills the 256 CUs for
+    // about three rounds or more; very deep K with few tiles (dgrad of the logits) stays on the 128x128 kernel
+    // (bf16 outputs only: with one workgroup per CU nothing hides the 8-bytes-per-element fp32 residual epilogue)
+    const bool big = g_nt256 == 1 ? (epi == EGO_EPI_BF16 && N % 256 == 0 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)) : (g_nt256 == 2);
+    if (big) {
+        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256), dim3(512), NT2_LDS, stream, a);
+        LAUNCH_CHECK();
+        return EGO_OK;
+    }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), NT_LDS, stream, a);
     LAUNCH_CHECK();

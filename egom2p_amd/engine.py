@@ -64,6 +64,19 @@ class Engine:
         self._alloc_workspaces()
         self.weights_dirty = True
         self._have_fwd = False
+        # optional: weight-gradient GEMMs on a side stream beside the dgrad / attention chain of the same layer, joined
+        # at every bucket boundary.  Measured on MI355X: parity-clean but 5 % SLOWER than one stream (the co-running
+        # kernels fight for LDS / L2), so it is off by default (EGOM2P_WGRAD_STREAM=1 enables it).
+        import os
+        self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("EGOM2P_WGRAD_STREAM", "0") == "1" else None
+
+    def _ring_next(self):
+        self._ring_i = (self._ring_i + 1) % len(self.ring_b)
+        return self.ring_b[self._ring_i]
+
+    def _join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     # ------------------------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -335,6 +348,9 @@ class Engine:
         R = max(RN, RM)
         self.dres = e(RM, D, dt=F32)               # decoder residual-stream gradient
         self.dres_b = e(RM, D)
+        self.ring_b = [e(R, D) for _ in range(4)]   # rotating bf16 copies of the residual-stream gradient (wgrad operands)
+        self._ring_i = 0
+        self.t_d3 = e(R, D)
         self.dctx = e(RN, D, dt=F32)
         self.dctx_b = e(RN, D)
         self.dxe = e(RN, D, dt=F32)                # encoder residual-stream gradient
@@ -361,12 +377,26 @@ class Engine:
         l = self.lin[name]
         if dX is not None:
             ops.gemm_nt(dY, l.wt, dX, rows, l.in_f, l.out_f, L.EPI_BF16, lda=dY.shape[-1], ldb=l.out_f, ldc=dX.shape[-1])
-        tiles = (l.out_f // 128) * (l.in_f // 128)
+        self._wgrad(l.g, dY, X, l.out_f, l.in_f, rows, ldp=dY.shape[-1], ldq=X.shape[-1])
+
+    def _wgrad(self, G, dY, X, Ni, Nj, rows, ldp, ldq, m_range=None):
+        """G[Ni,Nj] += dY^T X on the side stream (operands must stay untouched until the next _join_side)."""
+        tiles = (Ni // 128) * (Nj // 128)
         steps = max(1, (rows + 63) // 64)
         # one full round of workgroups (2 per CU x 256 CUs): tiles * splits <= 512, never a second, mostly empty round
-        splits = max(1, min(steps, 512 // tiles, self.slab.numel() // (l.out_f * l.in_f)))
-        ops.gemm_tn(dY, X, l.g, l.out_f, l.in_f, rows, splits=splits, slab=self.slab if splits > 1 else None,
-                    ldp=dY.shape[-1], ldq=X.shape[-1], ldc=l.in_f)
+        splits = 1 if m_range is not None else max(1, min(steps, 512 // tiles, self.slab.numel() // (Ni * Nj)))
+
+        def run():
+            ops.gemm_tn(dY, X, G, Ni, Nj, rows, m_range=m_range, splits=splits, slab=self.slab if splits > 1 else None,
+                        ldp=ldp, ldq=ldq, ldc=Nj)
+        if self.side is None:
+            run()
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                run()
 
     def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk):
         D = self.D
@@ -481,8 +511,10 @@ class Engine:
         self._lin_bwd(f"{pre}.mlp.fc2.weight", dres_b, w["h"], dh, rows)
         ops.swiglu_bwd(w["ab"], dh, dab, rows, Fp)
         self._lin_bwd(f"{pre}.mlp.fc13", dab, w["ln2"], dln, rows)
+        nb = self._ring_next()
         ops.layernorm_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],
-                          dx_in=dres, dx_bf16=dres_b)
+                          dx_in=dres, dx_bf16=nb)
+        return nb
 
     def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke):
         D, B = self.D, self.B
@@ -490,8 +522,10 @@ class Engine:
         self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
         self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, Nq, 1, B, Nq, Nq)
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
+        nb = self._ring_next()
         ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
-                          dx_in=dres, dx_bf16=dres_b)
+                          dx_in=dres, dx_bf16=nb)
+        return nb
 
     def backward(self, gscale=1.0, bucket_done: Optional[Callable[[str, int, int], None]] = None):
         """Backward of the last forward; gradients are ACCUMULATED into the flat grad buffer scaled by
@@ -508,6 +542,7 @@ class Engine:
         bmap = {n: (lo, hi) for n, lo, hi in self.buckets}
 
         def done(name):
+            self._join_side()          # the bucket's weight gradients come from the side stream
             if bucket_done is not None:
                 lo, hi = bmap[name]
                 bucket_done(name, lo, hi)
@@ -520,10 +555,10 @@ class Engine:
             lg = self.logits[V]
             ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods)
             ops.gemm_nt(lg, l.wt, self.dyn, ub, D, V, L.EPI_BF16, m_range=self.ranges[c], lda=V, ldb=V, ldc=D)
-            ops.gemm_tn(lg, self.yn, l.g, V, D, ub, m_range=self.ranges[c], ldp=V, ldq=D, ldc=D)
+            self._wgrad(l.g, lg, self.yn, V, D, ub, ldp=V, ldq=D, m_range=self.ranges[c])
         for m in reversed(mods):
             done(f"dec_table.{m.name}" if cfg.share_embedding else f"to_logits.{m.name}")
-        dres, dres_b = self.dres, self.dres_b
+        dres, dres_b = self.dres, self._ring_next()
         ops.layernorm_bwd(self.dyn, self.y_out[:RM], self.st_dn[0], self.st_dn[1], self.p["decoder_norm.weight"], dres,
                           self.g["decoder_norm.weight"], dx_in=None, dx_bf16=dres_b, dy_row=self.perm)
 
@@ -531,21 +566,23 @@ class Engine:
         first_ctx = True
         for i in reversed(range(cfg.decoder_depth)):
             w, pre = self.dec[i], f"decoder.{i}"
-            self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
+            dres_b = self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
             # cross attention
             dxo, dq, dkv, dln = self.t_d, self.t_d2, self.t_2d, self.t_d
             self._lin_bwd(f"{pre}.cross_attn.proj.weight", dres_b, w["xo"], dxo, RM)
             self._attn_bwd(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], dxo, w["lse_x"], dq, dkv, self.zero_b, ce["n_valid"],
                            1, 0, B, M, N)
             self._lin_bwd(f"{pre}.cross_attn.q.weight", dq, w["qn"], dln, RM)
+            nb = self._ring_next()
             ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
-                              self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=dres_b)
-            dcn = self.t_d2
+                              self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=nb)
+            dres_b = nb
+            dcn = self.t_d3            # not t_d2: dq is still being read by the q-projection wgrad on the side stream
             self._lin_bwd(f"{pre}.cross_attn.kv.weight", dkv, w["cn"], dcn, RN)
             ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
                               self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx)
             first_ctx = False
-            self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"])
+            dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"])
             done(pre)
         if cfg.decoder_depth == 0:
             self.dctx[:RN].zero_()
@@ -560,7 +597,7 @@ class Engine:
         ops.bias_grad(self.dctx_b, RN, D, self.g["decoder_proj_context.bias"])
         dxe_n = self.t_d
         self._lin_bwd("decoder_proj_context.weight", self.dctx_b, self.xe, dxe_n, RN)
-        dxe, dxe_b = self.dxe, self.dxe_b
+        dxe, dxe_b = self.dxe, self._ring_next()
         ops.layernorm_bwd(dxe_n, self.x_enc_out[:RN], self.st_en[0], self.st_en[1], self.p["encoder_norm.weight"], dxe,
                           self.g["encoder_norm.weight"], dx_in=None, dx_bf16=dxe_b)
         done("bridge")
@@ -568,8 +605,8 @@ class Engine:
         # ---- encoder layers
         for i in reversed(range(cfg.encoder_depth)):
             w, pre = self.enc[i], f"encoder.{i}"
-            self._mlp_bwd(pre, w, dxe, dxe_b, RN, w["xm"])
-            self._self_attn_bwd(pre, "attn", w, dxe, dxe_b, RN, N, ce["ks"], ce["ke"])
+            dxe_b = self._mlp_bwd(pre, w, dxe, dxe_b, RN, w["xm"])
+            dxe_b = self._self_attn_bwd(pre, "attn", w, dxe, dxe_b, RN, N, ce["ks"], ce["ke"])
             done(pre)
         # encoder input embeddings: token rows, mod_emb (emb is used twice: x = tok + emb and context += emb)
         ops.embed_bwd([self.g[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
@@ -578,6 +615,7 @@ class Engine:
         done("mod_emb")
         for m in reversed(mods):
             done(f"enc_table.{m.name}")
+        self._join_side()
         self._have_fwd = False
 
     def zero_grad(self):

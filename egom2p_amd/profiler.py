@@ -22,13 +22,21 @@ class KernelTimer:
         self.records = []      # (class, flops, bytes, start_event, end_event)
 
     def _wrap(self, name, fn, cost):
+        import os
+        detail = os.environ.get("EGOM2P_PROFILE_DETAIL") == "1"
+
         def wrapped(*a, **k):
             flops, nbytes = cost(*a, **k)
+            nm = name
+            if detail and name == "gemm_nt":
+                nm = f"gemm_nt[{a[3]}x{a[4]}x{a[5]} epi{a[6] if len(a) > 6 else k.get('epi', 0)}{' rng' if k.get('m_range') is not None else ''}]"
+            elif detail and name == "gemm_tn":
+                nm = f"gemm_tn[{a[5]}x{a[3]}x{a[4]} s{k.get('splits', 1)}]"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **k)
             e.record()
-            self.records.append((name, flops, nbytes, s, e))
+            self.records.append((nm, flops, nbytes, s, e))
             return r
         return wrapped
 

@@ -18,7 +18,8 @@ def main():
     dev = "cuda"
     res = {}
     nt_shapes = [(32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (32768, 768, 4096),
-                 (16144, 64000, 768), (16144, 768, 64000), (4096, 4096, 4096), (8192, 8192, 8192)]
+                 (16144, 64000, 768), (16144, 768, 64000), (4096, 4096, 4096), (8192, 8192, 8192),
+                 (65536, 768, 768), (65536, 2304, 768), (65536, 768, 2048), (65536, 1536, 768), (32288, 64000, 768), (32288, 768, 64000)]
     for M, N, K in nt_shapes:
         A = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
         B = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
@@ -26,7 +27,7 @@ def main():
         t = timeit(lambda: ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16))
         res[f"nt {M}x{N}x{K}"] = round(2.0 * M * N * K / t / 1e12, 1)
         del A, B, C
-    for M, N, K in [(32768, 768, 768), (32768, 768, 2048)]:
+    for M, N, K in [(32768, 768, 768), (32768, 768, 2048), (65536, 768, 768), (65536, 768, 2048)]:
         A = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
         B = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
         R = torch.randn(M, N, device=dev)
