@@ -628,11 +628,11 @@ class Engine:
         self._have_fwd = False
 
     # ------------------------------------------------------------------------------------ generation (config 4)
-    def _alloc_infer(self, B: int, Nmax: int, Mmax: int):
+    def _alloc_infer(self, B: int, Nmax: int, Mmax: int, fresh: bool = False):
         """One set of buffers (nothing is saved for a backward) for encoder-decoder passes of the ROAR / CFG
         generation path, sized for up to Nmax encoder rows and Mmax decoder rows per sample."""
         key = (B, Nmax, Mmax)
-        if getattr(self, "_infer_key", None) is not None and all(a >= b for a, b in zip(self._infer_key, key)):
+        if not fresh and getattr(self, "_infer_key", None) is not None and all(a >= b for a, b in zip(self._infer_key, key)):
             return self._iw
         D, Fp, H, dev = self.D, self.Fp, self.H, self.dev
         R = B * max(Nmax, Mmax)
@@ -652,12 +652,13 @@ class Engine:
             zero_b=torch.zeros(B, device=dev, dtype=I32), full_m=torch.zeros(B, device=dev, dtype=I32),
             dslot=torch.zeros(B * Mmax, device=dev, dtype=I32), dtok=torch.zeros(B * Mmax, device=dev, dtype=I32),
         )
-        self._iw, self._infer_key = w, key
+        if not fresh:
+            self._iw, self._infer_key = w, key
         return w
 
     @torch.no_grad()
     def infer_logits(self, enc_inputs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], n_enc: int, target: str,
-                     dec_pos: torch.Tensor) -> torch.Tensor:
+                     dec_pos: torch.Tensor, out: Optional[torch.Tensor] = None, ws: Optional[dict] = None) -> torch.Tensor:
         """One encoder-decoder pass of `forward_enc_dec_roar_batched` (egom2p/models/generate.py:747-766).
 
         enc_inputs: modality -> (ids int64 [B, n], input_mask bool [B, n]); n_enc = rows kept per sample (the
@@ -672,7 +673,7 @@ class Engine:
         tm = byname[target]
         B, M = dec_pos.shape
         N = int(n_enc)
-        w = self._alloc_infer(B, max(N, 1), M)
+        w = ws if ws is not None else self._alloc_infer(B, max(N, 1), M)
         side = w["side"]
         RN, RM = B * N, B * M
         x = None
@@ -727,9 +728,48 @@ class Engine:
             y, yn = yn, y
         ops.layernorm_fwd(y[:RM], self.p["decoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
         l = self.lin[self.logit_key[tm.name]]
-        logits = torch.empty(RM, tm.vocab_size, device=self.dev, dtype=BF16)
+        logits = out if out is not None else torch.empty(RM, tm.vocab_size, device=self.dev, dtype=BF16)
         ops.gemm_nt(w["ln"], l.wb, logits, RM, tm.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=tm.vocab_size)
         return logits.view(B, M, tm.vocab_size)
+
+    def infer_logits_graphed(self, enc_inputs, n_enc: int, target: str, dec_pos: torch.Tensor) -> torch.Tensor:
+        """`infer_logits` replayed from a captured hipGraph (BASELINE config 4: "hipGraph-captured decode").
+        One graph per pass shape (batch, modalities, N, M, target): inputs are copied into static buffers, the
+        ~300 kernel launches of a pass are replayed with one host call, the logits land in a static buffer
+        that stays valid until the next replay of the same graph."""
+        if self.weights_dirty:
+            self.refresh_weights()
+        B, M = dec_pos.shape
+        names = tuple(m.name for m in self.mods if m.name in enc_inputs)
+        key = (B, names, int(n_enc), M, target)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            V = {m.name: m for m in self.mods}[target].vocab_size
+            # a captured graph bakes in device addresses: it owns its workspace for as long as it lives
+            st = {"ws": self._alloc_infer(B, max(int(n_enc), 1), M, fresh=True),
+                  "ids": {n: enc_inputs[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names},
+                  "mask": {n: enc_inputs[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names},
+                  "pos": dec_pos.to(self.dev, I32).clone(),
+                  "out": torch.empty(B * M, V, device=self.dev, dtype=BF16)}
+            run = lambda: self.infer_logits({n: (st["ids"][n], st["mask"][n]) for n in names}, n_enc, target, st["pos"], out=st["out"], ws=st["ws"])
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                           # warm-up (lazy inits happen here, not in the capture)
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run()
+            g = graphs[key] = (graph, st)
+        graph, st = g
+        for n in names:
+            st["ids"][n].copy_(enc_inputs[n][0].reshape(B, -1))
+            st["mask"][n].copy_(enc_inputs[n][1].reshape(B, -1))
+        st["pos"].copy_(dec_pos)
+        graph.replay()
+        V = st["out"].shape[1]
+        return st["out"].view(B, M, V)
 
     @torch.no_grad()
     def forward_logits(self, mod_dict, dec_order=None) -> Dict[str, torch.Tensor]:

@@ -103,9 +103,10 @@ def init_full_input_modality(mod_dict, modality_info, domain, device, eos_id=3):
 
 # ---------------------------------------------------------------------------------------------- sampler
 class GenerationSampler:
-    def __init__(self, model):
+    def __init__(self, model, use_graphs: bool = False):
         self.model = model
         self.engine = model.engine if hasattr(model, "engine") else model
+        self.use_graphs = use_graphs           # replay each encoder-decoder pass from a captured hipGraph
 
     # one encoder-decoder pass (forward_enc_dec_roar_batched, generate.py:747-766) ---------------------
     def _logits(self, mod_dict, target_mod, mod_pos):
@@ -121,6 +122,8 @@ class GenerationSampler:
             enc[m.name] = (ids, mask)
         # rows kept by forward_mask_encoder_generation = max unmasked count over the batch (:413-415)
         n_enc = int(torch.stack([(~v[1]).sum(1) for v in enc.values()]).sum(0).max().item()) if enc else 0
+        if self.use_graphs:
+            return eng.infer_logits_graphed(enc, n_enc, target_mod, mod_pos).clone()
         return eng.infer_logits(enc, n_enc, target_mod, mod_pos)
 
     def roar_order(self, target_mask: torch.Tensor, num_select: int, seed: Optional[int]) -> torch.Tensor:

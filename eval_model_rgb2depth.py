@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--bench", type=int, default=0, help="time this many generate() calls after one warm-up")
+    ap.add_argument("--no-graphs", action="store_true", help="launch kernels one by one instead of replaying hipGraphs")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     device = "cuda"
@@ -46,7 +47,7 @@ def main():
         # weights_only=True: nothing from the file is executed
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu", weights_only=True)["model"])
     model.eval()
-    sampler = GenerationSampler(model)
+    sampler = GenerationSampler(model, use_graphs=not args.no_graphs)
 
     cond_domains, target_domains, tokens_per_target = ["tok_rgb"], ["tok_depth"], [5120]
     schedule = build_chained_generation_schedules(

@@ -136,3 +136,28 @@ def test_generate_end_to_end_runs():
     assert t.shape == (2, 5120) and int(t.min()) >= 0 and int(t.max()) < 64000
     assert out["tok_depth"]["target_mask"].all() and not out["tok_depth"]["input_mask"].any()
     assert sample["tok_depth"]["input_mask"].all()            # the caller's dict is untouched (deepcopy, :1046)
+
+
+def test_hipgraph_replay_is_bitwise_identical():
+    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=64, n_dec=64)
+    eng.init_random(4)
+    pos = torch.randperm(5120, device=DEV)[:300][None]
+    for trial in range(3):                       # first call captures, later calls replay with new inputs
+        ids = synth.randint(f"g{trial}.rgb", (1, 5120), 64000, seed=trial).to(DEV)
+        mask = torch.zeros(1, 5120, dtype=torch.bool, device=DEV)
+        mask[:, torch.randperm(5120, device=DEV)[:1120]] = True      # 4000 inputs kept
+        enc = {"tok_rgb": (ids, mask)}
+        eager = eng.infer_logits(enc, 4000, "tok_depth", pos).clone()
+        graphed = eng.infer_logits_graphed(enc, 4000, "tok_depth", pos)
+        assert torch.equal(eager, graphed)
+        pos = torch.roll(pos, 7, dims=1)
+    # the sampler produces the same tokens with and without graphs (same seeds)
+    sample = {"tok_rgb": {"tensor": synth.randint("gg.rgb", (1, 5, 32, 32), 64000, seed=1).to(DEV)}}
+    sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 1, 5120, DEV)
+    sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+                                             [2.0], ["constant"], cfg_grow_conditioning=True)
+    a = GenerationSampler(eng, use_graphs=False).generate(sample, sch, top_p=0.8, seed=3)["tok_depth"]["tensor"]
+    b = GenerationSampler(eng, use_graphs=True).generate(sample, sch, top_p=0.8, seed=3)["tok_depth"]["tensor"]
+    assert torch.equal(a, b)
