@@ -99,8 +99,11 @@ __device__ __forceinline__ void store_rows_bf16(bf16_t* dst, const f32x16 (&t)[2
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // grid: x = (batch, head), y = query tile.  Workgroups b and b + 8 share an XCD (round-robin dispatch) and
+    // gridDim.x = B * H is a multiple of 8 for the model's shapes, so every tile of one (batch, head) lands on the
+    // same XCD and its K / V stay in that XCD's L2 (with the tile index fastest, all 8 L2s re-fetched them).
+    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+    const int q0 = blockIdx.y * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
 
@@ -265,8 +268,11 @@ __global__ void attn_delta_kernel(const bf16_t* O, long o_bs, long o_rs, const b
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // grid: x = (batch, head), y = query tile.  Workgroups b and b + 8 share an XCD (round-robin dispatch) and
+    // gridDim.x = B * H is a multiple of 8 for the model's shapes, so every tile of one (batch, head) lands on the
+    // same XCD and its K / V stay in that XCD's L2 (with the tile index fastest, all 8 L2s re-fetched them).
+    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+    const int q0 = blockIdx.y * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
 
@@ -386,8 +392,8 @@ constexpr int DKV_LDS = 4 * TILE_BYTES + 2 * 1024;
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;       // (batch, head) fastest: see attn_fwd_kernel
+    const int kw0 = blockIdx.y * 128 + wave * 32;
     const int kl = lane & 31, hh = lane >> 5;
     const int kidx = kw0 + kl;
     const int krow = min(kidx, p.Nk - 1);
@@ -553,7 +559,7 @@ extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
-    EGO_LAUNCH(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H, (Nq + 127) / 128, 1), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -582,9 +588,9 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
                            (const bf16_t*)dO, do_bs, do_rs, DELTA, B, H, Nq);
         LAUNCH_CHECK();
     }
-    EGO_LAUNCH(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H, (Nq + 127) / 128, 1), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
-    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H, (Nk + 127) / 128, 1), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
