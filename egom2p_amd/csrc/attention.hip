@@ -454,12 +454,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     for (int i = 0; i < 16; ++i) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
     const float c_sc = p.scale * LOG2E;
 
-    const int nqt = (p.Nq + 63) >> 6;
-    load_tile(0);
-    store_tile(0);
+    // Query rows whose interval touches this workgroup's 128 keys (block-diagonal decoder masks and padded
+    // encoder keys leave many (q tile, key block) pairs empty): scan the intervals once, walk only that range.
+    int q_first = INT_MAX, q_last = -1;
+    {
+        const int kb0 = blockIdx.y * 128, kb1 = kb0 + 128;
+        for (int r = tid; r < p.Nq; r += 256) {
+            int a = KSb[r * p.r_rs], e = min(KEb[r * p.r_rs], p.Nk);
+            if (e <= a) { a = 0; e = p.Nk; }
+            if (a < kb1 && e > kb0) { q_first = min(q_first, r); q_last = max(q_last, r); }
+        }
+        q_first = wave_min_i(q_first); q_last = wave_max_i(q_last);
+        int* red = (int*)(smem + AUX_OFF);
+        if (lane == 0) { red[wave] = q_first; red[4 + wave] = q_last; }
+        __syncthreads();
+        q_first = min(min(red[0], red[1]), min(red[2], red[3]));
+        q_last = max(max(red[4], red[5]), max(red[6], red[7]));
+        __syncthreads();
+    }
+    const int qt0 = (q_last < 0) ? 0 : (q_first >> 6);
+    const int nqt = (q_last < 0) ? 0 : ((q_last >> 6) + 1);
+    if (qt0 < nqt) {
+        load_tile(qt0);
+        store_tile(0);
+    }
     __syncthreads();
-    for (int qt = 0; qt < nqt; ++qt) {
-        const int s_ = qt & 1;
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int s_ = (qt - qt0) & 1;
         if (qt + 1 < nqt) load_tile(qt + 1);
         const char* Qt = smem + s_ * 2 * TILE_BYTES;
         const char* Gt = Qt + TILE_BYTES;
