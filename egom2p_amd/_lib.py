@@ -104,3 +104,8 @@ def load():
 def check(rc: int, what: str):
     if rc != 0:
         raise EgoHipError(f"{what} failed: {'bad arguments' if rc == 1 else 'kernel launch failed'} (rc={rc})")
+
+
+def tn256_enabled() -> bool:
+    """EGO_GEMM_TN256=0 keeps every wgrad on the 128x128 kernel (read by the library at load time too)."""
+    return os.environ.get("EGO_GEMM_TN256", "1") != "0"

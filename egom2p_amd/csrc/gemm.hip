@@ -626,6 +626,149 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN kernel, 256x256 tile, 8 waves, staggered half-phases (large wgrads; see gemm_nt256_kernel for the
+// schedule and its hazard analysis - identical here).  Operand tiles are [64 m][256 cols] (512-B rows),
+// every fragment comes from two ds_read_b64_tr_b16 (inline asm, so hipcc does not drain the LDS-DMA in
+// front of them); their completion is awaited explicitly after the barrier that opens each COMPUTE segment.
+// Requires M % 64 == 0 (no zero-filled tail step); the launcher falls back to gemm_tn_kernel otherwise.
+// ---------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_pair(unsigned a) {     // rows r0..r0+3 and r0+4..r0+7 of one 16-column block
+    return join8(tr_read<OFF>(a), tr_read<OFF + 4 * 512>(a));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+
+    int M = p.M;
+    long moff = 0;
+    if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
+    const int tiles_j = p.Nj / 256, ntile = (p.Ni / 256) * tiles_j;
+    const int split = blockIdx.x / ntile;
+    const int t = xcd_remap(blockIdx.x % ntile, ntile);
+    const int i0 = (t / tiles_j) * 256, j0 = (t % tiles_j) * 256;
+    const int nsteps = M / BK;
+    const int per = (nsteps + p.splits - 1) / p.splits;
+    const int st0 = split * per, st1 = min(nsteps, st0 + per);
+
+    const bf16_t* P = p.P + moff * p.ldp + i0;
+    const bf16_t* Q = p.Q + moff * p.ldq + j0;
+    // LDS-DMA: wave instruction (wave*4 + j) fills tile rows 2(wave*4+j), +1 (512 B each); 32-byte chunk swizzle on the source
+    long p_off[4], q_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 2 * (wave * 4 + j) + (lane >> 5), s16 = lane & 31;
+        const int c = (((s16 >> 1) ^ tn_f(r)) << 1) | (s16 & 1);
+        p_off[j] = (long)r * p.ldp + c * 8;
+        q_off[j] = (long)r * p.ldq + c * 8;
+    }
+    auto dma = [&](int s, int m0, int j) {
+        glds16(P + (long)m0 * p.ldp + p_off[j], smem + s * S2_BYTES + (wave * 4 + j) * 1024);
+        glds16(Q + (long)m0 * p.ldq + q_off[j], smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024);
+    };
+    // transposed-read addresses (stage 0): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16
+    // block; 16-column block ci of row r sits at 32-byte chunk ci ^ tn_f(r), and tn_f is the same for r0, r0+4, r0+32
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int r0 = 8 * g + tq, f = tn_f(r0);
+    unsigned pa[8], qa[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pa[i] = lds0 + r0 * 512 + ((grp * 8 + (i ^ f)) << 5) + tp * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qa[i] = lds0 + T2_BYTES + r0 * 512 + (((wc * 4 + i) ^ f) << 5) + tp * 8;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 pf[4][2], qf[2][2];
+
+    if (st0 < st1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma(0, st0 * BK, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar_pinned();
+        if (grp == 1) bar_pinned();
+
+#define TLOAD_P(QM, SO)                                                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                   \
+        pf[mi][0] = tr_pair<0>(pa[(QM) * 4 + mi] + (SO));                                                \
+        pf[mi][1] = tr_pair<32 * 512>(pa[(QM) * 4 + mi] + (SO));                                         \
+    }
+#define TLOAD_Q(QN, SO)                                                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                   \
+        qf[ni][0] = tr_pair<0>(qa[(QN) * 2 + ni] + (SO));                                                \
+        qf[ni][1] = tr_pair<32 * 512>(qa[(QN) * 2 + ni] + (SO));                                         \
+    }
+#define TCOMPUTE(QM, QN)                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)    \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
+            acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+                qf[ni][ks], pf[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                     \
+    __builtin_amdgcn_s_setprio(0);
+
+        for (int st = st0; st < st1; ++st) {
+            const unsigned so = ((st - st0) & 1) * S2_BYTES;
+            const int sn = ((st - st0) & 1) ^ 1, mn = (st + 1) * BK;
+            const bool more = st + 1 < st1;
+            TLOAD_P(0, so) TLOAD_Q(0, so)
+            if (more && grp == 1) { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); }
+            bar_pinned();
+            TCOMPUTE(0, 0)
+            bar_pinned();
+            TLOAD_Q(1, so)
+            if (more) { if (grp == 1) { dma(sn, mn, 3); } else { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); } }
+            bar_pinned();
+            TCOMPUTE(0, 1)
+            bar_pinned();
+            TLOAD_P(1, so)
+            if (more && grp == 0) { dma(sn, mn, 3); }
+            bar_pinned();
+            TCOMPUTE(1, 1)
+            bar_pinned();
+            TLOAD_Q(0, so)
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar_pinned();
+            TCOMPUTE(1, 0)
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar_pinned();
+        }
+#undef TLOAD_P
+#undef TLOAD_Q
+#undef TCOMPUTE
+        if (grp == 0) bar_pinned();
+    }
+
+    // epilogue: lane owns output row gi (i index), 4 consecutive columns gj..gj+3
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gi = i0 + grp * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gj = j0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            const f32x4 v = acc[i][j];
+            if (p.splits > 1) {
+                *(f32x4*)(p.slab + ((long)split * p.Ni + gi) * p.Nj + gj) = v;
+            } else {
+                float* dst;
+                if (gi < p.split_row) { if (gi >= p.rows0) continue; dst = p.C0 + (long)gi * p.ldc + gj; }
+                else { if (gi - p.split_row >= p.rows1) continue; dst = p.C1 + (long)(gi - p.split_row) * p.ldc + gj; }
+                f32x4 o = *(f32x4*)dst;
+                o += v;
+                *(f32x4*)dst = o;
+            }
+        }
+    }
+}
+
 // C[row][:] += sum_s slab[s][row][:]   (deterministic split-K combine)
 __global__ void tn_reduce_kernel(const float* slab, float* C0, float* C1, long ldc, int split_row, int rows0,
                                  int rows1, int Ni, int Nj, int splits) {
@@ -644,12 +787,17 @@ __global__ void tn_reduce_kernel(const float* slab, float* C0, float* C1, long l
 
 int g_nt_wgs = 512;        // persistent grid: 2 workgroups (64 KiB LDS each) per CU x 256 CUs
 int g_nt256 = 1;           // use the 256x256 staggered kernel for large shapes (EGO_GEMM_NT256=0 disables)
+int g_tn256 = 1;           // same for the wgrad kernel (EGO_GEMM_TN256=0 disables, 2 forces it where legal)
+long g_tn256_min_area = 512L * 1024L;   // smallest Ni*Nj sent to the 256x256 kernel
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
+    if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
+    if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
     if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
     if (const char* e = getenv("EGO_GEMM_NT256")) g_nt256 = atoi(e);
     g_attr_done = true;
@@ -693,8 +841,15 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (!C1) { split_row = Ni; rows1 = 0; }
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
-    const int tiles = (Ni / BM) * (Nj / BN);
-    EGO_LAUNCH(gemm_tn_kernel, dim3(tiles * splits), dim3(256), GEMM_LDS, stream, a);
+    // 256x256 staggered kernel: whole 64-row steps only (no device-side row range), one workgroup per CU
+    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && (M % BK == 0) && !m_range;
+    const int tiles256 = (Ni / 256) * (Nj / 256);
+    if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
+        EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT2_LDS, stream, a);
+    } else {
+        const int tiles = (Ni / BM) * (Nj / BN);
+        EGO_LAUNCH(gemm_tn_kernel, dim3(tiles * splits), dim3(256), GEMM_LDS, stream, a);
+    }
     LAUNCH_CHECK();
     if (splits > 1) {
         const long total = (long)Ni * (Nj / 4);

@@ -363,7 +363,7 @@ class Engine:
         self.t_2f = e(R, 2 * Fp)
         self.dyn = torch.zeros(RM, D, device=dev, dtype=BF16)
         self.delta = e(B, H, max(N, M), dt=F32)
-        self.slab = e(48 * 1024 * 1024 // 4 * 1, dt=F32) if True else None   # 48 MiB of split-K partials
+        self.slab = e(64 * 1024 * 1024 // 4, dt=F32)   # 64 MiB of split-K partials (256 workgroups x 256 KiB)
         self.gscale = torch.ones(1, device=dev, dtype=F32)
 
     # ------------------------------------------------------------------------------------ small helpers
@@ -381,10 +381,7 @@ class Engine:
 
     def _wgrad(self, G, dY, X, Ni, Nj, rows, ldp, ldq, m_range=None):
         """G[Ni,Nj] += dY^T X on the side stream (operands must stay untouched until the next _join_side)."""
-        tiles = (Ni // 128) * (Nj // 128)
-        steps = max(1, (rows + 63) // 64)
-        # one full round of workgroups (2 per CU x 256 CUs): tiles * splits <= 512, never a second, mostly empty round
-        splits = 1 if m_range is not None else max(1, min(steps, 512 // tiles, self.slab.numel() // (Ni * Nj)))
+        splits = ops.tn_splits(Ni, Nj, rows, self.slab.numel(), ranged=m_range is not None)
 
         def run():
             ops.gemm_tn(dY, X, G, Ni, Nj, rows, m_range=m_range, splits=splits, slab=self.slab if splits > 1 else None,

@@ -3,6 +3,7 @@ call goes straight to the C-ABI of libegom2p_hip.so.  Used by the engine and by 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -65,6 +66,18 @@ def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_ra
     rows0 = (split_row if rows0 is None else rows0)
     check(L.load().ego_gemm_tn_bf16(_p(P), ldp, _p(Q), ldq, _p(C0), _p(C1), ldc, split_row, rows0, rows1, _p(m_range), Ni, Nj,
                                     M, splits, _p(slab), _stream()), "ego_gemm_tn_bf16")
+
+
+def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, wgs128=512, wgs256=256):
+    """Split-K factor for `gemm_tn`: one full round of workgroups and no more.  Large whole-step shapes run on the
+    256x256 kernel (1 workgroup per CU), the rest on the 128x128 kernel (2 per CU); mirrors the launcher's choice."""
+    if ranged:
+        return 1
+    steps = max(1, (rows + 63) // 64)
+    cap = max(1, slab_numel // (Ni * Nj))
+    if Ni % 256 == 0 and Nj % 256 == 0 and rows % 64 == 0 and Ni * Nj >= int(os.environ.get("EGO_GEMM_TN256_AREA", 512 * 1024)) and L.tn256_enabled():
+        return max(1, min(steps, wgs256 // ((Ni // 256) * (Nj // 256)), cap))
+    return max(1, min(steps, wgs128 // ((Ni // 128) * (Nj // 128)), cap))
 
 
 def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):

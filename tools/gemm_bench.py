@@ -20,6 +20,7 @@ def main():
     nt_shapes = [(32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (32768, 768, 4096),
                  (16144, 64000, 768), (16144, 768, 64000), (4096, 4096, 4096), (8192, 8192, 8192),
                  (65536, 768, 768), (65536, 2304, 768), (65536, 768, 2048), (65536, 1536, 768), (32288, 64000, 768), (32288, 768, 64000)]
+    if os.environ.get('SKIP_NT') == '1': nt_shapes = []
     for M, N, K in nt_shapes:
         A = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
         B = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
@@ -27,7 +28,7 @@ def main():
         t = timeit(lambda: ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16))
         res[f"nt {M}x{N}x{K}"] = round(2.0 * M * N * K / t / 1e12, 1)
         del A, B, C
-    for M, N, K in [(32768, 768, 768), (32768, 768, 2048), (65536, 768, 768), (65536, 768, 2048)]:
+    for M, N, K in ([] if os.environ.get('SKIP_NT') == '1' else [(32768, 768, 768), (32768, 768, 2048), (65536, 768, 768), (65536, 768, 2048)]):
         A = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
         B = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
         R = torch.randn(M, N, device=dev)
@@ -36,13 +37,12 @@ def main():
         res[f"nt_resid {M}x{N}x{K}"] = round(2.0 * M * N * K / t / 1e12, 1)
         del A, B, C, R
     if os.environ.get("SKIP_TN") != "1":
-        slab = torch.empty(48 * 1024 * 1024 // 4, device=dev)
-        for M, Ni, Nj in [(32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (16144, 64000, 768)]:
+        slab = torch.empty(64 * 1024 * 1024 // 4, device=dev)
+        for M, Ni, Nj in [(65536, 768, 768), (32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (65536, 2304, 768), (65536, 4096, 768), (65536, 768, 2048), (65536, 1536, 768), (16144, 64000, 768)]:
             P = (torch.rand(M, Ni, device=dev) * 2 - 1).bfloat16()
             Q = (torch.rand(M, Nj, device=dev) * 2 - 1).bfloat16()
             C = torch.zeros(Ni, Nj, device=dev)
-            tiles = (Ni // 128) * (Nj // 128)
-            splits = max(1, min((M + 63) // 64, int(os.environ.get('TN_WGS', '512')) // tiles, slab.numel() // (Ni * Nj)))
+            splits = ops.tn_splits(Ni, Nj, M, slab.numel(), wgs256=int(os.environ.get('TN_WGS256', '256')))
             t = timeit(lambda: ops.gemm_tn(P, Q, C, Ni, Nj, M, splits=splits, slab=slab if splits > 1 else None))
             res[f"tn {M}x{Ni}x{Nj} s{splits}"] = round(2.0 * M * Ni * Nj / t / 1e12, 1)
             del P, Q, C
