@@ -93,6 +93,18 @@ __device__ __forceinline__ void store_rows_bf16(bf16_t* dst, const f32x16 (&t)[2
         }
 }
 
+// K / V (or Q / dO) tiles go straight from global memory into LDS (LDS-DMA, no VGPR staging): wave instruction i of
+// wave w fills tile rows 8(2w+i)..+7 - lane l lands in row +(l>>3), 16-byte slot l&7, so it fetches the logical chunk
+// that the swizzle keeps in that slot.  Rows past `nrows` re-read the last row (finite, and always masked).
+__device__ __forceinline__ void dma_tile64(const bf16_t* base, long rs, int row0, int nrows, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (2 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3));
+        glds16(base + (long)min(row0 + r, nrows - 1) * rs + c * 8, tile + (2 * wave + i) * 1024);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -126,24 +138,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
-    u32x4 rk[2], rv[2];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int key = kt * 64 + r;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            rk[i] = (key < p.Nk) ? *(const u32x4*)(Kb + (long)key * p.k_rs + c * 8) : z;
-            rv[i] = (key < p.Nk) ? *(const u32x4*)(Vb + (long)key * p.v_rs + c * 8) : z;
-        }
-    };
-    auto store_tile = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rk[i];
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rv[i];
-        }
+    auto dma_tile = [&](int kt, int s) {
+        dma_tile64(Kb, p.k_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES, wave, lane);
+        dma_tile64(Vb, p.v_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
     };
 
     f32x16 ot[2];
@@ -151,14 +148,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
     float m = NEG_BIG, l = 0.f;
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
+    if (kt0 < kt1) dma_tile(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int s_ = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1);
+        if (kt + 1 < kt1) dma_tile(kt + 1, s_ ^ 1);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
 
@@ -230,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int db = 0; db < 2; ++db)
                 ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, db, sp, lane), pf, ot[db], 0, 0, 0);
         }
-        if (kt + 1 < kt1) store_tile(s_ ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -265,7 +260,7 @@ __global__ void attn_delta_kernel(const bf16_t* O, long o_bs, long o_rs, const b
 // ---------------------------------------------------------------------------------------------
 // backward, query-major: dQ
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grid: x = (batch, head), y = query tile.  Workgroups b and b + 8 share an XCD (round-robin dispatch) and
@@ -302,81 +297,61 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
-    u32x4 rk[2], rv[2];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int key = kt * 64 + r;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            rk[i] = (key < p.Nk) ? *(const u32x4*)(Kb + (long)key * p.k_rs + c * 8) : z;
-            rv[i] = (key < p.Nk) ? *(const u32x4*)(Vb + (long)key * p.v_rs + c * 8) : z;
-        }
-    };
-    auto store_tile = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rk[i];
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rv[i];
-        }
+    auto dma_tile = [&](int kt, int s) {
+        dma_tile64(Kb, p.k_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES, wave, lane);
+        dma_tile64(Vb, p.v_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
     };
 
     f32x16 dqt[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
+    if (kt0 < kt1) dma_tile(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int s_ = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1);
+        if (kt + 1 < kt1) dma_tile(kt + 1, s_ ^ 1);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
-        f32x16 st[2], dp[2];
+        // dS^T = P o (dP^T - delta) * scale.  Interior tiles (every row of the wave sees all 64 keys) skip the
+        // interval compares: at head_dim 64 these kernels are VALU-bound, not MFMA-bound.  The two 32-key halves
+        // are processed one after the other so that only one S / dP accumulator pair is live (3 waves per SIMD).
+        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { st[kb][i] = 0.f; dp[kb][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
-                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp[kb], 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp, 0, 0, 0);
             }
-        }
-        // dS^T = P o (dP^T - delta) * scale.  Interior tiles (every row of the wave sees all 64 keys) skip the
-        // interval compares: at head_dim 64 these kernels are VALU-bound, not MFMA-bound.
-        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
-        if (full) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -lse2));
-                    st[kb][r] = pv * __builtin_fmaf(dp[kb][r], gsc, -dgs);
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -lse2));
+                    st[r] = pv * __builtin_fmaf(dp[r], gsc, -dgs);
                 }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
                     const bool ok = (kidx >= ks && kidx < ke);
-                    const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -lse2)) : 0.f;
-                    st[kb][r] = pv * __builtin_fmaf(dp[kb][r], gsc, -dgs);
+                    const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -lse2)) : 0.f;
+                    st[r] = pv * __builtin_fmaf(dp[r], gsc, -dgs);
                 }
-        }
+            }
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-            const bf16x8 dsf = pack8(st[sp >> 1], sp & 1);
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8 dsf = pack8(st, x);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, db, sp, lane), dsf, dqt[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db)
+                    dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, db, 2 * kb + x, lane), dsf, dqt[db], 0, 0, 0);
+            }
         }
-        if (kt + 1 < kt1) store_tile(s_ ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (q0 + ql < p.Nq)
@@ -414,34 +389,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int* KSb = p.ks + b * p.r_bs;
     const int* KEb = p.ke + b * p.r_bs;
 
-    u32x4 rq[2], rg[2];
+    // Q / dO tiles arrive by LDS-DMA (dma_tile64); the four per-row scalars are staged through registers of wave 0
     float a_lse = 0.f, a_del = 0.f;
     int a_ks = INT_MAX, a_ke = 0;
-    auto load_tile = [&](int qt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            const int row = qt * 64 + r;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            rq[i] = (row < p.Nq) ? *(const u32x4*)(Qb + (long)row * p.q_rs + c * 8) : z;
-            rg[i] = (row < p.Nq) ? *(const u32x4*)(Gb + (long)row * p.do_rs + c * 8) : z;
-        }
+    auto load_tile = [&](int qt, int s) {
+        dma_tile64(Qb, p.q_rs, qt * 64, p.Nq, smem + s * 2 * TILE_BYTES, wave, lane);
+        dma_tile64(Gb, p.do_rs, qt * 64, p.Nq, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
         if (tid < 64) {
             const int row = qt * 64 + tid;
             if (row < p.Nq) {
                 a_lse = LSEb[row]; a_del = DELb[row] * p.scale;      // delta * scale: dS = P * fma(dP, scale, -delta*scale)
                 a_ks = KSb[row * p.r_rs]; a_ke = min(KEb[row * p.r_rs], p.Nk);
                 if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
-            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }
+            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }   // (the DMA re-read row Nq-1: finite, masked)
         }
     };
-    auto store_tile = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + att_off(r, c)) = rq[i];
-            *(u32x4*)(smem + s * 2 * TILE_BYTES + TILE_BYTES + att_off(r, c)) = rg[i];
-        }
+    auto store_aux = [&](int s) {
         if (tid < 64) {
             float* af = (float*)(smem + AUX_OFF + s * 1024);
             int* ai = (int*)(smem + AUX_OFF + s * 1024 + 512);
@@ -475,13 +438,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int qt0 = (q_last < 0) ? 0 : (q_first >> 6);
     const int nqt = (q_last < 0) ? 0 : ((q_last >> 6) + 1);
     if (qt0 < nqt) {
-        load_tile(qt0);
-        store_tile(0);
+        load_tile(qt0, 0);
+        store_aux(0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int qt = qt0; qt < nqt; ++qt) {
         const int s_ = (qt - qt0) & 1;
-        if (qt + 1 < nqt) load_tile(qt + 1);
+        if (qt + 1 < nqt) load_tile(qt + 1, s_ ^ 1);       // that stage was last read before the previous barrier
         const char* Qt = smem + s_ * 2 * TILE_BYTES;
         const char* Gt = Qt + TILE_BYTES;
         const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);
@@ -553,7 +517,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                 }
             }
         }
-        if (qt + 1 < nqt) store_tile(s_ ^ 1);
+        if (qt + 1 < nqt) store_aux(s_ ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (kidx < p.Nk) {

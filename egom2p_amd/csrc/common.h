@@ -69,6 +69,13 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
 }
 
+// 16 B per lane straight from global memory into LDS (LDS-DMA): dst = wave-uniform base + lane * 16.
+// Counts in vmcnt; any swizzle has to be applied on the SOURCE address.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 // XCD-aware block remap (bijective for any grid): blocks b, b+8 share an XCD under round-robin
 // dispatch, so give each XCD a contiguous run of tile ids (speed only, never correctness).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

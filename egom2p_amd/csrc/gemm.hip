@@ -46,11 +46,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    // 16 B per lane straight into LDS (LDS-DMA): dst = wave-uniform base + lane * 16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel, persistent.  Each workgroup walks a strided list of 128x128 output tiles; the K loop runs

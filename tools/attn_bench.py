@@ -22,7 +22,7 @@ def main():
     dqkv = torch.empty_like(qkv)
     lse = torch.empty(B, H, N, device=dev); delta = torch.empty(B, H, N, device=dev)
     res = {}
-    for kind in ("full", "half", "aligned", "blocks"):
+    for kind in os.environ.get("KINDS", "full,half,aligned,blocks").split(","):
         ks = torch.zeros(B, N, dtype=torch.int32, device=dev); ke = torch.full((B, N), N, dtype=torch.int32, device=dev)
         pairs = float(B) * N * N
         if kind == "half":
