@@ -44,6 +44,16 @@ struct AttnArgs {
     bf16_t* dV; long dv_bs, dv_rs;
 };
 
+// Workgroup id -> ((batch, head) pair, tile), pair index fastest.  The hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs and B * H is a multiple of 8 for the model's shapes, so every tile of one pair lands on
+// the same XCD and its K / V (or Q / dO) stream is fetched into one L2 only (with the tile index fastest all 8 L2s
+// re-fetched it: 2x slower on the block-diagonal decoder mask).  Measured alternatives that walk the tiles of one
+// pair back to back on an XCD (smaller live set per L2) were equal on full masks and 5-25 % slower on block masks.
+__device__ __forceinline__ void pair_tile(int id, int pairs, int& pair, int& tile) {
+    pair = id % pairs;
+    tile = id / pairs;
+}
+
 // byte offset of 16-byte chunk c16 (0..7) of row r in the swizzled [64][64] bf16 image
 __device__ __forceinline__ int att_off(int r, int c16) {
     const int v = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
@@ -68,6 +78,31 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int db, int sp, int 
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
+}
+
+// The same operand through inline-asm reads: per lane four base addresses [db][lo/hi row] (the swizzle term does not
+// depend on sp), k-step sp and the tile's position are immediates.  tr_issue starts the 8 reads of k-steps SP0 and
+// SP0+1 (both d blocks); the caller waits with lgkm_wait_tied before joining the halves.
+struct TrAddr { unsigned a[2][2]; };
+__device__ __forceinline__ TrAddr tr_addr(unsigned lds_base, int lane) {
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3, h = g >> 1;
+    TrAddr r;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+            r.a[db][w] = lds_base + att_off(4 * h + q + 8 * w, 4 * db + 2 * (g & 1) + (p >> 1)) + (p & 1) * 8;
+    return r;
+}
+template <int TOFF, int SP0>
+__device__ __forceinline__ void tr_issue(const TrAddr& A, unsigned stage_off, s16x4 (&v)[4][2]) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        v[db][0] = tr_read<TOFF + SP0 * 2048>(A.a[db][0] + stage_off);
+        v[db][1] = tr_read<TOFF + SP0 * 2048>(A.a[db][1] + stage_off);
+        v[2 + db][0] = tr_read<TOFF + (SP0 + 1) * 2048>(A.a[db][0] + stage_off);
+        v[2 + db][1] = tr_read<TOFF + (SP0 + 1) * 2048>(A.a[db][1] + stage_off);
+    }
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int x) {
@@ -95,27 +130,42 @@ __device__ __forceinline__ void store_rows_bf16(bf16_t* dst, const f32x16 (&t)[2
 
 // K / V (or Q / dO) tiles go straight from global memory into LDS (LDS-DMA, no VGPR staging): wave instruction i of
 // wave w fills tile rows 8(2w+i)..+7 - lane l lands in row +(l>>3), 16-byte slot l&7, so it fetches the logical chunk
-// that the swizzle keeps in that slot.  Rows past `nrows` re-read the last row (finite, and always masked).
-__device__ __forceinline__ void dma_tile64(const bf16_t* base, long rs, int row0, int nrows, char* tile, int wave, int lane) {
+// that the swizzle keeps in that slot.
+// with buffer loads: the (batch, head) slice is a raw buffer whose size ends with row nrows-1 (rows past it read as
+// zeros, like the reference's padding), the lane's two piece offsets are loop-invariant VGPRs, the tile's position
+// is the scalar offset and the LDS destination sits in M0 - no vector ALU work per tile.
+struct DmaOff { unsigned o[2]; };     // byte offsets of this lane's two pieces inside a 64-row tile
+__device__ __forceinline__ DmaOff dma_off(long rs, int wave, int lane) {
+    DmaOff d;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = 8 * (2 * wave + i) + (lane >> 3);
-        const int c = (lane & 7) ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3));
-        glds16(base + (long)min(row0 + r, nrows - 1) * rs + c * 8, tile + (2 * wave + i) * 1024);
+        d.o[i] = (unsigned)(r * (int)rs * 2 + (((lane & 7) ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3))) << 4));
     }
+    return d;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const bf16_t* base, long rs, int nrows) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)(nrows - 1) * rs * 2 + 128), 0x00020000);
+}
+__device__ __forceinline__ void dma_tile64(__amdgpu_buffer_rsrc_t rsrc, long rs, const DmaOff& off, int row0, char* tile, int wave) {
+    const int soff = row0 * (int)rs * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (2 * wave + i) * 1024), 16,
+                                                 off.o[i], soff, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // grid: x = (batch, head), y = query tile.  Workgroups b and b + 8 share an XCD (round-robin dispatch) and
-    // gridDim.x = B * H is a multiple of 8 for the model's shapes, so every tile of one (batch, head) lands on the
-    // same XCD and its K / V stay in that XCD's L2 (with the tile index fastest, all 8 L2s re-fetched them).
-    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
-    const int q0 = blockIdx.y * 128 + wave * 32;
+constexpr int FWD_STAGES = 3;
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    const int h = pair % p.H, b = pair / p.H;
+    const int q0 = tile * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
 
@@ -124,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
     const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
     const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
-    int* rng = (int*)(smem + 4 * TILE_BYTES);
+    int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
     if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
     __syncthreads();
     const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
@@ -138,22 +188,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
+    const DmaOff kvoff = dma_off(p.k_rs, wave, lane);               // k_rs == v_rs (checked by the launcher)
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(Kb, p.k_rs, p.Nk), vrs = slice_rsrc(Vb, p.v_rs, p.Nk);
     auto dma_tile = [&](int kt, int s) {
-        dma_tile64(Kb, p.k_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES, wave, lane);
-        dma_tile64(Vb, p.v_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        dma_tile64(krs, p.k_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(vrs, p.v_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
     };
 
     f32x16 ot[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
     float m = NEG_BIG, l = 0.f;
+    const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
 
+    // K / V ring of FWD_STAGES tiles, filled two tiles ahead; every tile is 4 DMA instructions of this wave, so
+    // "at most 4 outstanding" means the older tile has landed.
     if (kt0 < kt1) dma_tile(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (kt0 + 1 < kt1) {
+        dma_tile(kt0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    int s_ = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int s_ = (kt - kt0) & 1;
-        if (kt + 1 < kt1) dma_tile(kt + 1, s_ ^ 1);      // that stage was last read before the previous barrier
+        const bool ahead = kt + 2 < kt1;
+        if (ahead) dma_tile(kt + 2, s_ >= 1 ? s_ - 1 : 2);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
 
@@ -166,6 +227,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int s = 0; s < 4; ++s)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
         }
+        s16x4 va[4][2], vb[4][2];
+        tr_issue<TILE_BYTES, 0>(tra, s_ * 2 * TILE_BYTES, va);
         // online softmax in the raw-score domain: p = exp2(s * sc - m * sc) is ONE fma + one v_exp per element
         // (this kernel is VALU-bound at head_dim 64); `m` tracks the running max of the raw scores (sc >= 0).
         const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
@@ -218,15 +281,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 }
         }
         l += rs;
+        // O^T += V^T P^T: V fragments by asm transposed reads (k-steps 0,1 were started before the softmax)
+        tr_issue<TILE_BYTES, 2>(tra, s_ * 2 * TILE_BYTES, vb);
+        lgkm_wait_tied<8>(va);
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-            const bf16x8 pf = pack8(st[sp >> 1], sp & 1);
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8 pf = pack8(st[0], x);
 #pragma unroll
             for (int db = 0; db < 2; ++db)
-                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, db, sp, lane), pf, ot[db], 0, 0, 0);
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(va[2 * x + db][0], va[2 * x + db][1]), pf, ot[db], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lgkm_wait_tied<0>(vb);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8 pf = pack8(st[1], x);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(vb[2 * x + db][0], vb[2 * x + db][1]), pf, ot[db], 0, 0, 0);
+        }
+        if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        s_ = (s_ == 2) ? 0 : s_ + 1;
     }
 
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -262,12 +338,11 @@ __global__ void attn_delta_kernel(const bf16_t* O, long o_bs, long o_rs, const b
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // grid: x = (batch, head), y = query tile.  Workgroups b and b + 8 share an XCD (round-robin dispatch) and
-    // gridDim.x = B * H is a multiple of 8 for the model's shapes, so every tile of one (batch, head) lands on the
-    // same XCD and its K / V stay in that XCD's L2 (with the tile index fastest, all 8 L2s re-fetched them).
-    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
-    const int q0 = blockIdx.y * 128 + wave * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    const int h = pair % p.H, b = pair / p.H;
+    const int q0 = tile * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
 
@@ -297,9 +372,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
+    const DmaOff kvoff = dma_off(p.k_rs, wave, lane);               // k_rs == v_rs (checked by the launcher)
+    const __amdgpu_buffer_rsrc_t krs = slice_rsrc(Kb, p.k_rs, p.Nk), vrs = slice_rsrc(Vb, p.v_rs, p.Nk);
     auto dma_tile = [&](int kt, int s) {
-        dma_tile64(Kb, p.k_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES, wave, lane);
-        dma_tile64(Vb, p.v_rs, kt * 64, p.Nk, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        dma_tile64(krs, p.k_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(vrs, p.v_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
     };
 
     f32x16 dqt[2];
@@ -366,9 +443,11 @@ constexpr int DKV_LDS = 4 * TILE_BYTES + 2 * 1024;
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;       // (batch, head) fastest: see attn_fwd_kernel
-    const int kw0 = blockIdx.y * 128 + wave * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    const int h = pair % p.H, b = pair / p.H;
+    const int kw0 = tile * 128 + wave * 32;
     const int kl = lane & 31, hh = lane >> 5;
     const int kidx = kw0 + kl;
     const int krow = min(kidx, p.Nk - 1);
@@ -392,16 +471,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // Q / dO tiles arrive by LDS-DMA (dma_tile64); the four per-row scalars are staged through registers of wave 0
     float a_lse = 0.f, a_del = 0.f;
     int a_ks = INT_MAX, a_ke = 0;
+    const DmaOff qoff = dma_off(p.q_rs, wave, lane), goff = dma_off(p.do_rs, wave, lane);
+    const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(Qb, p.q_rs, p.Nq), grs = slice_rsrc(Gb, p.do_rs, p.Nq);
     auto load_tile = [&](int qt, int s) {
-        dma_tile64(Qb, p.q_rs, qt * 64, p.Nq, smem + s * 2 * TILE_BYTES, wave, lane);
-        dma_tile64(Gb, p.do_rs, qt * 64, p.Nq, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        dma_tile64(qrs, p.q_rs, qoff, qt * 64, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(grs, p.do_rs, goff, qt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
         if (tid < 64) {
             const int row = qt * 64 + tid;
             if (row < p.Nq) {
                 a_lse = LSEb[row]; a_del = DELb[row] * p.scale;      // delta * scale: dS = P * fma(dP, scale, -delta*scale)
                 a_ks = KSb[row * p.r_rs]; a_ke = min(KEb[row * p.r_rs], p.Nk);
                 if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
-            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }   // (the DMA re-read row Nq-1: finite, masked)
+            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }   // (the DMA zero-fills rows past Nq)
         }
     };
     auto store_aux = [&](int s) {
@@ -421,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // encoder keys leave many (q tile, key block) pairs empty): scan the intervals once, walk only that range.
     int q_first = INT_MAX, q_last = -1;
     {
-        const int kb0 = blockIdx.y * 128, kb1 = kb0 + 128;
+        const int kb0 = tile * 128, kb1 = kb0 + 128;
         for (int r = tid; r < p.Nq; r += 256) {
             int a = KSb[r * p.r_rs], e = min(KEb[r * p.r_rs], p.Nk);
             if (e <= a) { a = 0; e = p.Nk; }
@@ -528,7 +609,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 bool check(const AttnArgs& a) {
-    return a.B > 0 && a.H > 0 && a.Nq > 0 && a.Nk > 0 && a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 &&
+    // the K and V slices share their lane offsets in the LDS-DMA (packed kv / qkv rows): one row stride for both
+    return a.k_rs == a.v_rs && a.B > 0 && a.H > 0 && a.Nq > 0 && a.Nk > 0 && a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 &&
            a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0;
 }
 
@@ -545,7 +627,7 @@ extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
-    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H, (Nq + 127) / 128, 1), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -574,9 +656,9 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
                            (const bf16_t*)dO, do_bs, do_rs, DELTA, B, H, Nq);
         LAUNCH_CHECK();
     }
-    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H, (Nq + 127) / 128, 1), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
-    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H, (Nk + 127) / 128, 1), dim3(256), 0, stream, a);
+    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

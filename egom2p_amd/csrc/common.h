@@ -69,6 +69,35 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt (its fence covers global
+// memory), which would wait for every in-flight LDS-DMA / global store instead of the counted ones
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ds_read_b64_tr_b16 as inline asm: hipcc does not see an LDS read, so it neither drains in-flight LDS-DMA in front
+// of it (it does for the builtin) nor tracks its completion - the caller waits (s_waitcnt lgkmcnt) before the use,
+// through an asm statement that names the results so that no consumer (or register copy) can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int N>   // wait until at most N LDS operations are outstanding; the 8 listed results are final afterwards
+__device__ __forceinline__ void lgkm_wait_tied(s16x4 (&v)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1])
+                 : "n"(N) : "memory");
+}
+
 // 16 B per lane straight from global memory into LDS (LDS-DMA): dst = wave-uniform base + lane * 16.
 // Counts in vmcnt; any swizzle has to be applied on the SOURCE address.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {

@@ -38,15 +38,6 @@ struct NTArgs {
     int M, N, K, epi;
 };
 
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt (its fence covers
-// global memory), which would expose the completion latency of the epilogue's global stores on every tile
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // NT kernel, persistent.  Each workgroup walks a strided list of 128x128 output tiles; the K loop runs
 // as ONE pipeline across tile boundaries (the first K-step of the next tile is loaded under the last
@@ -450,17 +441,6 @@ __device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) <<
 // LDS-DMA is in flight (it cannot prove the DMA targets the other stage), which serialises load and
 // compute; the asm form is invisible to that pass.  Its completion is therefore OUR job: every use is
 // behind an explicit `s_waitcnt lgkmcnt(0)` + sched_barrier (cdna_hip_programming.md 5.7 item 1, rule 18).
-template <int OFF>
-__device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
-    s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
 
 template <int S>   // LDS stage
 __device__ __forceinline__ void tn_compute(const unsigned (&pb)[4], const unsigned (&qb)[4], f32x4 (&acc)[4][4]) {
