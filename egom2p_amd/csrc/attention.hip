@@ -44,14 +44,25 @@ struct AttnArgs {
     bf16_t* dV; long dv_bs, dv_rs;
 };
 
-// Workgroup id -> ((batch, head) pair, tile), pair index fastest.  The hardware deals consecutive workgroup ids
-// round-robin over the 8 XCDs and B * H is a multiple of 8 for the model's shapes, so every tile of one pair lands on
-// the same XCD and its K / V (or Q / dO) stream is fetched into one L2 only (with the tile index fastest all 8 L2s
-// re-fetched it: 2x slower on the block-diagonal decoder mask).  Measured alternatives that walk the tiles of one
-// pair back to back on an XCD (smaller live set per L2) were equal on full masks and 5-25 % slower on block masks.
-__device__ __forceinline__ void pair_tile(int id, int pairs, int& pair, int& tile) {
-    pair = id % pairs;
-    tile = id / pairs;
+// Workgroup id -> ((batch, head) pair, tile).  The hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs and the resident workgroups are a contiguous id range.  B * H is a multiple of 8 for the model's shapes, so
+// both orders below keep every tile of one pair on ONE XCD (with the tile index fastest over the whole grid all 8
+// L2s re-fetched each K / V stream: 2x slower on the block-diagonal decoder mask).
+//   * walk = true (one interval per batch row: encoder self-attention, cross-attention - every tile costs the
+//     same): consecutive ids of an XCD walk the tiles of ONE pair, so only 96 / tiles pairs are alive per L2 and
+//     their K / V (Q / dO) streams stay in its 4 MB.  rocprofv3 FETCH_SIZE at B 32: 2.55 GB -> 0.35 GB per forward
+//     launch, 6-7 % less time (the streams came from HBM: qkv of one micro-batch is 300 MB, beyond the 256 MB MALL).
+//   * walk = false (per-row intervals, block-diagonal decoder mask: tile costs differ up to 2x): pair index
+//     fastest; the tile walk ran 5-25 % slower there.
+__device__ __forceinline__ void pair_tile(int id, int pairs, int tiles, bool walk, int& pair, int& tile) {
+    if (walk && (pairs & 7) == 0) {
+        const int x = id & 7, j = id >> 3;
+        pair = (j / tiles) * 8 + x;
+        tile = j % tiles;
+    } else {
+        pair = id % pairs;
+        tile = id / pairs;
+    }
 }
 
 // byte offset of 16-byte chunk c16 (0..7) of row r in the swizzled [64][64] bf16 image
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);
     const int h = pair % p.H, b = pair / p.H;
     const int q0 = tile * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);
     const int h = pair % p.H, b = pair / p.H;
     const int q0 = tile * 128 + wave * 32;
     const int ql = lane & 31, hh = lane >> 5;
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, pair, tile);
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nk + 127) >> 7, p.r_rs == 0, pair, tile);
     const int h = pair % p.H, b = pair / p.H;
     const int kw0 = tile * 128 + wave * 32;
     const int kl = lane & 31, hh = lane >> 5;
