@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
 // schedule and its hazard analysis - identical here).  Operand tiles are [64 m][256 cols] (512-B rows),
 // every fragment comes from two ds_read_b64_tr_b16 (inline asm, so hipcc does not drain the LDS-DMA in
 // front of them); their completion is awaited explicitly after the barrier that opens each COMPUTE segment.
-// Requires M % 64 == 0 (no zero-filled tail step); the launcher falls back to gemm_tn_kernel otherwise.
+// A partial last step and device-side row ranges are handled by the buffer bounds (zero fill).
 // ---------------------------------------------------------------------------------------------
 template <int OFF>
 __device__ __forceinline__ bf16x8 tr_pair(unsigned a) {     // rows r0..r0+3 and r0+4..r0+7 of one 16-column block
@@ -626,24 +626,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     const int split = blockIdx.x / ntile;
     const int t = xcd_remap(blockIdx.x % ntile, ntile);
     const int i0 = (t / tiles_j) * 256, j0 = (t % tiles_j) * 256;
-    const int nsteps = M / BK;
+    const int nsteps = (M + BK - 1) / BK;
     const int per = (nsteps + p.splits - 1) / p.splits;
     const int st0 = split * per, st1 = min(nsteps, st0 + per);
 
-    const bf16_t* P = p.P + moff * p.ldp + i0;
-    const bf16_t* Q = p.Q + moff * p.ldq + j0;
-    // LDS-DMA: wave instruction (wave*4 + j) fills tile rows 2(wave*4+j), +1 (512 B each); 32-byte chunk swizzle on the source
-    long p_off[4], q_off[4];
+    // LDS-DMA by buffer loads: each operand panel [M rows][256 columns] is a raw buffer that ends with row M-1, so the
+    // rows of a last partial 64-row step read as zeros (they must contribute nothing - no tail path); the lane's piece
+    // offsets are loop-invariant, the step's position is the scalar offset.  Wave instruction (wave*4 + j) fills tile
+    // rows 2(wave*4+j), +1 (512 B each); 32-byte chunk swizzle on the source.  (The launcher guarantees < 4 GiB spans.)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.P + moff * p.ldp + i0), 0, (int)(unsigned)((long)(M - 1) * p.ldp * 2 + 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.Q + moff * p.ldq + j0), 0, (int)(unsigned)((long)(M - 1) * p.ldq * 2 + 512), 0x00020000);
+    unsigned p_off[4], q_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 2 * (wave * 4 + j) + (lane >> 5), s16 = lane & 31;
         const int c = (((s16 >> 1) ^ tn_f(r)) << 1) | (s16 & 1);
-        p_off[j] = (long)r * p.ldp + c * 8;
-        q_off[j] = (long)r * p.ldq + c * 8;
+        p_off[j] = (unsigned)(r * p.ldp * 2 + c * 16);
+        q_off[j] = (unsigned)(r * p.ldq * 2 + c * 16);
     }
     auto dma = [&](int s, int m0, int j) {
-        glds16(P + (long)m0 * p.ldp + p_off[j], smem + s * S2_BYTES + (wave * 4 + j) * 1024);
-        glds16(Q + (long)m0 * p.ldq + q_off[j], smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + (wave * 4 + j) * 1024),
+                                                 16, p_off[j], (int)((unsigned)m0 * (unsigned)(p.ldp * 2)), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024),
+                                                 16, q_off[j], (int)((unsigned)m0 * (unsigned)(p.ldq * 2)), 0, 0);
     };
     // transposed-read addresses (stage 0): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16
     // block; 16-column block ci of row r sits at 32-byte chunk ci ^ tn_f(r), and tn_f is the same for r0, r0+4, r0+32
@@ -816,8 +823,9 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (!C1) { split_row = Ni; rows1 = 0; }
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
-    // 256x256 staggered kernel: whole 64-row steps only (no device-side row range), one workgroup per CU
-    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && (M % BK == 0) && !m_range;
+    // 256x256 staggered kernel, one workgroup per CU: operand spans must fit the 32-bit buffer offsets
+    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && M > 0 &&
+                          (long)M * ldp * 2 < 0xfff00000L && (long)M * ldq * 2 < 0xfff00000L;
     const int tiles256 = (Ni / 256) * (Nj / 256);
     if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
         EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT2_LDS, stream, a);

@@ -95,6 +95,32 @@ def test_gemm_tn_split_rows_and_range():
         assert _rel(C1, ref[128:218]) < 1e-5
 
 
+def test_gemm_tn256_range_ragged_and_split_rows():
+    """the 256x256 kernel takes device row ranges and partial last steps through its buffer bounds (zero fill)"""
+    M, Ni, Nj = 900, 8192, 1024          # 32 x 4 tiles of 256 x 256 -> the launcher picks the 256 kernel
+    P = _bf(torch.randn(M, Ni, device=DEV))
+    Q = _bf(torch.randn(M, Nj, device=DEV))
+    C0 = torch.zeros(4000, Nj, device=DEV)
+    C1 = torch.zeros(4090, Nj, device=DEV)
+    rng = torch.tensor([100, 701], device=DEV, dtype=torch.int32)      # 701 rows: 10 full steps + 61 rows
+    ops.gemm_tn(P, Q, C0, Ni, Nj, M, C1=C1, split_row=4096, rows0=4000, rows1=4090, m_range=rng)
+    ref = P[100:801].float().t() @ Q[100:801].float()
+    assert _rel(C0, ref[:4000]) < 1e-5
+    assert _rel(C1, ref[4096:4096 + 4090]) < 1e-5
+    # empty range: nothing is added
+    C0.zero_()
+    ops.gemm_tn(P, Q, C0, Ni, Nj, M, C1=C1, split_row=4096, rows0=4000, rows1=4090,
+                m_range=torch.tensor([5, 0], device=DEV, dtype=torch.int32))
+    assert float(C0.abs().max()) == 0.0
+    # ragged M without a range, split-K
+    M2, Ni2, Nj2 = 64 * 7 + 13, 2304, 768
+    P2 = _bf(torch.randn(M2, Ni2, device=DEV)); Q2 = _bf(torch.randn(M2, Nj2, device=DEV))
+    G = torch.randn(Ni2, Nj2, device=DEV)
+    ref2 = G + P2.float().t() @ Q2.float()
+    ops.gemm_tn(P2, Q2, G, Ni2, Nj2, M2, splits=8, slab=torch.empty(8, Ni2, Nj2, device=DEV))
+    assert _rel(G, ref2) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, ks, ke, scale):
     """fp32 reference with the reference's masked_fill(-max) semantics. q:(B,H,Nq,64) k,v:(B,H,Nk,64); ks,ke:(B,Nq)."""
