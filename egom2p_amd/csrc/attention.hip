@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 // backward, key-major: dK, dV
 // ---------------------------------------------------------------------------------------------
 constexpr int AUX_OFF = 4 * TILE_BYTES;           // per stage: lse2[64] delta[64] ks[64] ke[64] = 1 KiB
-constexpr int DKV_LDS = 4 * TILE_BYTES + 2 * 1024;
+constexpr int AGG_OFF = AUX_OFF + 2 * 1024;         // per q tile {min ks, max ks, min ke, max ke}
+constexpr int DKV_MAX_QTILES = 512;
+constexpr int DKV_LDS = AGG_OFF + DKV_MAX_QTILES * 16;
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
@@ -508,17 +510,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
     const float c_sc = p.scale * LOG2E;
+    const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
 
-    // Query rows whose interval touches this workgroup's 128 keys (block-diagonal decoder masks and padded
-    // encoder keys leave many (q tile, key block) pairs empty): scan the intervals once, walk only that range.
+    // One pass over the intervals of this batch row: per 64-row q tile the four extremes {min ks, max ks, min ke,
+    // max ke} go to LDS (flat rows count as ks = -1 / ke = Nk, rows past Nq as ks = INT_MAX / ke = 0, like the per-row
+    // copies below).  They give (a) the range of q tiles that can touch this workgroup's 128 keys - block-diagonal
+    // decoder masks and padded encoder keys leave most (q tile, key block) pairs empty - and (b) the per-tile
+    // "skip" / "every row sees all my keys" decisions of each wave as scalar compares (no wave reductions per tile).
+    int* agg = (int*)(smem + AGG_OFF);
+    const int nq_tiles = (p.Nq + 63) >> 6;
+    for (int base = wave * 64; base < nq_tiles * 64; base += 256) {
+        const int r = base + lane;
+        int a = INT_MAX, e = 0;
+        if (r < p.Nq) {
+            a = KSb[r * p.r_rs]; e = min(KEb[r * p.r_rs], p.Nk);
+            if (e <= a) { a = -1; e = p.Nk; }
+        }
+        const int a_min = wave_min_i(a), a_max = wave_max_i(a), e_min = wave_min_i(e), e_max = wave_max_i(e);
+        if (lane == 0) { int* g4 = agg + 4 * (base >> 6); g4[0] = a_min; g4[1] = a_max; g4[2] = e_min; g4[3] = e_max; }
+    }
+    __syncthreads();
     int q_first = INT_MAX, q_last = -1;
     {
         const int kb0 = tile * 128, kb1 = kb0 + 128;
-        for (int r = tid; r < p.Nq; r += 256) {
-            int a = KSb[r * p.r_rs], e = min(KEb[r * p.r_rs], p.Nk);
-            if (e <= a) { a = 0; e = p.Nk; }
-            if (a < kb1 && e > kb0) { q_first = min(q_first, r); q_last = max(q_last, r); }
-        }
+        for (int t = tid; t < nq_tiles; t += 256)
+            if (max(agg[4 * t], 0) < kb1 && agg[4 * t + 3] > kb0) { q_first = min(q_first, t); q_last = max(q_last, t); }
         q_first = wave_min_i(q_first); q_last = wave_max_i(q_last);
         int* red = (int*)(smem + AUX_OFF);
         if (lane == 0) { red[wave] = q_first; red[4 + wave] = q_last; }
@@ -527,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         q_last = max(max(red[4], red[5]), max(red[6], red[7]));
         __syncthreads();
     }
-    const int qt0 = (q_last < 0) ? 0 : (q_first >> 6);
-    const int nqt = (q_last < 0) ? 0 : ((q_last >> 6) + 1);
+    const int qt0 = (q_last < 0) ? 0 : q_first;
+    const int nqt = (q_last < 0) ? 0 : q_last + 1;
     if (qt0 < nqt) {
         load_tile(qt0, 0);
         store_aux(0);
@@ -543,12 +559,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);
         const int* ai = (const int*)(smem + AUX_OFF + s_ * 1024 + 512);
 
-        // does any row of this q tile look at this wave's 32 keys?
-        int t_ks = ai[lane], t_ke = ai[64 + lane];
+        // does any row of this q tile look at this wave's 32 keys, and do all of them see all 32?  (scalar)
+        const int g_ksmin = __builtin_amdgcn_readfirstlane(agg[4 * qt]), g_ksmax = __builtin_amdgcn_readfirstlane(agg[4 * qt + 1]);
+        const int g_kemin = __builtin_amdgcn_readfirstlane(agg[4 * qt + 2]), hi = __builtin_amdgcn_readfirstlane(agg[4 * qt + 3]);
         // (flat rows carry ks = -1, rows beyond Nq carry ks = INT_MAX: both force the general path)
-        const bool tile_full = wave_min_i((t_ks >= 0 && t_ks <= kw0 && t_ke >= kw0 + 32) ? 1 : 0) != 0;
-        t_ks = (t_ks < 0) ? 0 : t_ks;
-        const int lo = wave_min_i(t_ks), hi = wave_max_i(t_ke);
+        const bool tile_full = g_ksmin >= 0 && g_ksmax <= kw0 && g_kemin >= kw0 + 32;
+        const int lo = max(g_ksmin, 0);
         if (hi > kw0 && lo < kw0 + 32) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -559,6 +575,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                 for (int s = 0; s < 4; ++s) {
                     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, qb, s, lane), kf[s], st, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gt, qb, s, lane), vf[s], dp, 0, 0, 0);
+                }
+                // dO / Q fragments for dV^T and dK^T (asm transposed reads): in flight under the exp / scale arithmetic
+                s16x4 gfr[4][2], qfr[4][2];
+                if (qb == 0) {
+                    tr_issue<TILE_BYTES, 0>(tra, s_ * 2 * TILE_BYTES, gfr);
+                    tr_issue<0, 0>(tra, s_ * 2 * TILE_BYTES, qfr);
+                } else {
+                    tr_issue<TILE_BYTES, 2>(tra, s_ * 2 * TILE_BYTES, gfr);
+                    tr_issue<0, 2>(tra, s_ * 2 * TILE_BYTES, qfr);
                 }
                 f32x16 pv, ds;
                 if (tile_full) {
@@ -597,14 +622,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     }
                 }
                 }
+                lgkm_wait_tied<0>(gfr);
+                lgkm_wait_tied<0>(qfr);
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
-                    const int sp = 2 * qb + x;
                     const bf16x8 pf = pack8(pv, x), dsf = pack8(ds, x);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Gt, db, sp, lane), pf, dvt[db], 0, 0, 0);
-                        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, db, sp, lane), dsf, dkt[db], 0, 0, 0);
+                        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 * x + db][0], gfr[2 * x + db][1]), pf, dvt[db], 0, 0, 0);
+                        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 * x + db][0], qfr[2 * x + db][1]), dsf, dkt[db], 0, 0, 0);
                     }
                 }
             }
@@ -660,6 +686,7 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
+    if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
     {
         const long waves = (long)B * Nq;
         const int blocks = (int)((waves * 64 + 255) / 256);
