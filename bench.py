@@ -156,6 +156,16 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": dom[0], "achieved": dom[1]["tflops"], "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
                            "launches": dom[1]["calls"], "avg_launch_ms": dom[1]["ms"] / dom[1]["calls"]}
+        # HBM-side bytes per launch of that kernel: PMC counters need a rocprofv3 wrapper around the process, so they
+        # are collected by the command recorded in profiles/pmc_latest.json (same workload and micro-batch) and read here
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            ent = pmc.get("abi", {}).get(dom[0])
+            if ent and pmc.get("micro_batch") == args.micro_batch and args.model == "egom2p_base_12e_12d_swiglu_nobias":
+                out["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/pmc_latest.json)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = dom[1]["bytes"] / dom[1]["calls"]
         out["kernel_breakdown"] = {k: {"ms": round(v["ms"], 3), "calls": v["calls"], "tflops": round(v["tflops"], 1),
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

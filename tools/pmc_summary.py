@@ -41,7 +41,22 @@ def main():
         w_kb, n2 = write.get(cls, (0.0, n))
         out[cls] = {"launches": n, "fetch_bytes_per_launch": 2.0 * f_kb * 1024 / n, "write_bytes_per_launch": w_kb * 1024 / max(n2, 1),
                     "traffic_bytes_per_launch": 2.0 * f_kb * 1024 / n + w_kb * 1024 / max(n2, 1)}
-    json.dump({"note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    # C-ABI level classes (what bench.py's KernelTimer brackets): both device kernels of one entry point together
+    abi = {}
+    for entry, parts in (("gemm_nt", ("gemm_nt", "gemm_nt256")), ("gemm_tn", ("gemm_tn", "gemm_tn256")),
+                         ("attn_bwd", ("attn_bwd_dq", "attn_bwd_dkv")), ("attn_fwd", ("attn_fwd",))):
+        have = [out[k] for k in parts if k in out]
+        if not have:
+            continue
+        n = sum(h["launches"] for h in have) if entry != "attn_bwd" else have[0]["launches"]
+        tot = sum(h["traffic_bytes_per_launch"] * h["launches"] for h in have)
+        abi[entry] = {"launches": n, "traffic_bytes_per_launch": tot / n}
+    meta = {"note": "HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE doubled "
+                    "per the gfx950 correction (MI355X_MICROARCH.md, HBM); counter units KiB -> bytes",
+            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --clips-per-gpu 32 --steps 1 "
+                       "--warmup 0 --no-cpu-baseline --no-kernel-profile",
+            "micro_batch": 32, "kernels": out, "abi": abi}
+    json.dump(meta, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
