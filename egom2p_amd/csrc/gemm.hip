@@ -245,6 +245,12 @@ __device__ __forceinline__ void bar_pinned() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Persistent: a workgroup walks tiles id, id + gridDim.x, ... as ONE pipeline.  The last K-step of a tile fetches
+// K-tile 0 of the next tile (so no tile start waits for memory), the bf16 epilogue runs in two 128-row passes through
+// the stage that K-step left free, and its global stores drain under the first K-step of the next tile.  At one
+// workgroup per CU nothing else would hide them: at K = 768 (12 K-steps per tile) the one-tile-per-workgroup form ran
+// at 820 TF/s against 1070 at long K.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant,
+// tile and K position are the scalar offset, rows past M / N read as zeros.  bf16 output only (EGO_EPI_BF16).
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,26 +262,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
     if (M <= 0) return;
     const int tiles_n = (p.N + 255) / 256;
-    // M may come from the device (row range of one modality): spread the tiles that really exist over the XCDs,
-    // the surplus workgroups of the launch leave at once (otherwise whole XCDs would own only empty tiles)
+    // M may come from the device (row range of one modality): spread the tiles that really exist over the XCDs
     const int ntiles = ((M + 255) / 256) * tiles_n;
     if ((int)blockIdx.x >= ntiles) return;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    const int row0 = (t / tiles_n) * 256, col0 = (t % tiles_n) * 256;
     const int nt = p.K / BK;
 
-    // LDS-DMA sources: wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + moff * p.lda), 0, (int)(unsigned)((long)(M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, (int)(unsigned)((long)(p.N - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
+    // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
+    unsigned a_off[4], b_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 8;
-        a_src[j] = p.A + (moff + min(row0 + r, M - 1)) * p.lda + c;
-        b_src[j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + c;
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
+        a_off[j] = (unsigned)(r * (int)p.lda * 2 + c);
+        b_off[j] = (unsigned)(r * (int)p.ldb * 2 + c);
     }
-    auto dma = [&](int s, int k0, int j) {
-        glds16(a_src[j] + k0, smem + s * S2_BYTES + (wave * 4 + j) * 1024);
-        glds16(b_src[j] + k0, smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024);
+    unsigned a_so = 0, b_so = 0;         // scalar byte offsets of the K-tile the next DMA fetches
+    auto dma = [&](int s, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + (wave * 4 + j) * 1024),
+                                                 16, a_off[j], (int)a_so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024),
+                                                 16, b_off[j], (int)b_so, 0, 0);
+    };
+    auto tile_origin = [&](int id, int& row0, int& col0) {
+        const int t = xcd_remap(id, ntiles);
+        row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * 256;
     };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
@@ -284,19 +297,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     for (int ks = 0; ks < 2; ++ks) foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
     const int a_base = grp * 128 * 128, b_base = T2_BYTES + wc * 64 * 128;
 
-    f32x4 acc[8][4];
+    int id = blockIdx.x, row0, col0;
+    tile_origin(id, row0, col0);
+    // prologue: K-tile 0 of the first tile by all waves
+    a_so = (unsigned)row0 * (unsigned)(p.lda * 2);
+    b_so = (unsigned)col0 * (unsigned)(p.ldb * 2);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], bq[2][2];
-
-    // prologue: K-tile 0 by all waves
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dma(0, 0, j);
+    for (int j = 0; j < 4; ++j) dma(0, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar_pinned();
-    if (grp == 1) bar_pinned();                              // stagger: group 1 runs one barrier behind
+    int cur = 0;                                             // stage that holds the K-tile about to be consumed
 
 #define LOAD_A(QM)                                                                                         \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
@@ -312,112 +322,97 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                 bq[ni][ks], af[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                       \
     __builtin_amdgcn_s_setprio(0);
 
-    for (int kt = 0; kt < nt; ++kt) {
-        const char* st = smem + (kt & 1) * S2_BYTES;
-        const int sn = (kt & 1) ^ 1, kn = (kt + 1) * BK;
-        const bool more = kt + 1 < nt;
-        // ---- phase 0: quadrant (0,0)
-        LOAD_A(0) LOAD_B(0)
-        if (more && grp == 1) { dma(sn, kn, 0); dma(sn, kn, 1); dma(sn, kn, 2); }
-        bar_pinned();
-        COMPUTE(0, 0)
-        bar_pinned();
-        // ---- phase 1: quadrant (0,1)
-        LOAD_B(1)
-        if (more) { if (grp == 1) { dma(sn, kn, 3); } else { dma(sn, kn, 0); dma(sn, kn, 1); dma(sn, kn, 2); } }
-        bar_pinned();
-        COMPUTE(0, 1)
-        bar_pinned();
-        // ---- phase 2: quadrant (1,1)
-        LOAD_A(1)
-        if (more && grp == 0) { dma(sn, kn, 3); }
-        bar_pinned();
-        COMPUTE(1, 1)
-        bar_pinned();
-        // ---- phase 3: quadrant (1,0)
-        LOAD_B(0)
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1: its DMA landed before slot 7 closes
-        bar_pinned();
-        COMPUTE(1, 0)
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0: same, end of its COMPUTE(3) (slot 7)
-        bar_pinned();
-    }
-#undef LOAD_A
-#undef LOAD_B
-#undef COMPUTE
-    if (grp == 0) bar_pinned();                              // match group 1's extra barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    while (true) {
+        const int next_id = id + gridDim.x;
+        const bool have_next = next_id < ntiles;
+        int nrow0 = 0, ncol0 = 0;
+        if (have_next) tile_origin(next_id, nrow0, ncol0);
 
-    // epilogue through LDS (all 128 KiB are free now): whole-row coalesced stores
-    if (p.epi == EGO_EPI_BF16) {
-        // image [256 rows][512 B]; 16-byte chunk c of row r at chunk c ^ (r & 15)
+        f32x4 acc[8][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ml = grp * 128 + i * 16 + (lane & 15);
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
-                const f32x4 v = acc[i][j];
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)(smem + ml * 512 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[4][2], bq[2][2];
+
+        if (grp == 1) bar_pinned();                              // stagger: group 1 runs one barrier behind
+        for (int kt = 0; kt < nt; ++kt) {
+            const char* st = smem + cur * S2_BYTES;
+            const int sn = cur ^ 1;
+            // what the DMA of this K-step fetches: the next K-tile of this tile, or K-tile 0 of the next tile
+            const bool more = (kt + 1 < nt) || have_next;
+            if (kt + 1 < nt) {
+                a_so = (unsigned)row0 * (unsigned)(p.lda * 2) + (unsigned)((kt + 1) * BK * 2);
+                b_so = (unsigned)col0 * (unsigned)(p.ldb * 2) + (unsigned)((kt + 1) * BK * 2);
+            } else {
+                a_so = (unsigned)nrow0 * (unsigned)(p.lda * 2);
+                b_so = (unsigned)ncol0 * (unsigned)(p.ldb * 2);
             }
+            // ---- phase 0: quadrant (0,0)
+            LOAD_A(0) LOAD_B(0)
+            if (more && grp == 1) { dma(sn, 0); dma(sn, 1); dma(sn, 2); }
+            bar_pinned();
+            COMPUTE(0, 0)
+            bar_pinned();
+            // ---- phase 1: quadrant (0,1)
+            LOAD_B(1)
+            if (more) { if (grp == 1) { dma(sn, 3); } else { dma(sn, 0); dma(sn, 1); dma(sn, 2); } }
+            bar_pinned();
+            COMPUTE(0, 1)
+            bar_pinned();
+            // ---- phase 2: quadrant (1,1)
+            LOAD_A(1)
+            if (more && grp == 0) { dma(sn, 3); }
+            bar_pinned();
+            COMPUTE(1, 1)
+            bar_pinned();
+            // ---- phase 3: quadrant (1,0)
+            LOAD_B(0)
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1: its DMA landed before slot 7 closes
+            bar_pinned();
+            COMPUTE(1, 0)
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0: same, end of its COMPUTE(3) (slot 7)
+            bar_pinned();
+            cur = sn;
         }
-        lds_barrier();
-#pragma unroll 4
-        for (int ps = 0; ps < 16; ++ps) {
-            const int r = ps * 16 + (tid >> 5), c = tid & 31;
-            const u32x4 v = *(const u32x4*)(smem + r * 512 + ((c ^ (r & 15)) << 4));
-            const int gm = row0 + r, gn = col0 + c * 8;
-            if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
-        }
-    } else {
+        if (grp == 0) bar_pinned();                              // match group 1's extra barrier: groups aligned again
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // epilogue: stage cur ^ 1 (consumed by the last K-step) is free, stage cur already holds the next tile's K-tile 0.
+        // Two passes of 128 rows: image [128 rows][512 B]; 16-byte chunk c of row r at chunk c ^ (r & 15); every wave
+        // store instruction then writes two whole 512-byte rows.
+        char* eb = smem + (cur ^ 1) * S2_BYTES;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {                               // 128 rows x 256 fp32 = 128 KiB per pass
-            // residual operand first: 16 independent 16-byte loads per lane in flight under the LDS transpose
-            const bool has_r = (p.epi == EGO_EPI_RESID || p.epi == EGO_EPI_BIAS_RESID);
-            f32x4 rr[16];
-            if (has_r) {
-#pragma unroll
-                for (int ps = 0; ps < 16; ++ps) {
-                    const int gm = row0 + half * 128 + ps * 8 + (tid >> 6), gn = col0 + (tid & 63) * 4;
-                    rr[ps] = (gm < M && gn < p.N) ? __builtin_nontemporal_load((const f32x4*)(p.R + (moff + gm) * p.ldr + gn))
-                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-            if (p.epi == EGO_EPI_BIAS_RESID) {
-                const int gn = col0 + (tid & 63) * 4;
-                if (gn < p.N) { const f32x4 b = *(const f32x4*)(p.bias + gn); bb = f32x4{round_bf16(b[0]), round_bf16(b[1]), round_bf16(b[2]), round_bf16(b[3])}; }
-            }
+        for (int half = 0; half < 2; ++half) {
             if (grp == half) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int ml = i * 16 + (lane & 15);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int c = wc * 16 + j * 4 + (lane >> 4);         // 16-byte chunk (4 fp32), 64 per row
-                        *(f32x4*)(smem + ml * 1024 + ((c ^ (ml & 15)) << 4)) = acc[i][j];
+                        const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
+                        const f32x4 v = acc[i][j];
+                        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2*)(eb + ml * 512 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
                     }
                 }
             }
             lds_barrier();
 #pragma unroll
-            for (int ps = 0; ps < 16; ++ps) {
-                const int r = ps * 8 + (tid >> 6), c = tid & 63;
-                f32x4 v = *(const f32x4*)(smem + r * 1024 + ((c ^ (r & 15)) << 4));
-                const int gm = row0 + half * 128 + r, gn = col0 + c * 4;
-                if (gm < M && gn < p.N) {
-                    if (has_r) {
-                        const f32x4 q = rr[ps];
-                        v = f32x4{q[0] + round_bf16(v[0] + bb[0]), q[1] + round_bf16(v[1] + bb[1]),
-                                  q[2] + round_bf16(v[2] + bb[2]), q[3] + round_bf16(v[3] + bb[3])};
-                    }
-                    *(f32x4*)((float*)p.C + (moff + gm) * p.ldc + gn) = v;
-                }
+            for (int ps = 0; ps < 8; ++ps) {
+                const int r = ps * 16 + (tid >> 5), c = tid & 31;
+                const u32x4 v = *(const u32x4*)(eb + r * 512 + ((c ^ (r & 15)) << 4));
+                const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
+                if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
             }
             lds_barrier();
         }
+        if (!have_next) break;
+        id = next_id; row0 = nrow0; col0 = ncol0;
     }
+#undef LOAD_A
+#undef LOAD_B
+#undef COMPUTE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -802,9 +797,10 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // measured on MI355X (tools/gemm_bench.py): the 256x256 kernel wins whenever the grid fills the 256 CUs for
     // about three rounds or more; very deep K with few tiles (dgrad of the logits) stays on the 128x128 kernel
     // (bf16 outputs only: with one workgroup per CU nothing hides the 8-bytes-per-element fp32 residual epilogue)
-    const bool big = g_nt256 == 1 ? (epi == EGO_EPI_BF16 && N % 256 == 0 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)) : (g_nt256 == 2);
+    const bool legal256 = epi == EGO_EPI_BF16 && N % 256 == 0 && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
+    const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)));
     if (big) {
-        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256), dim3(512), NT2_LDS, stream, a);
+        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT2_LDS, stream, a);
         LAUNCH_CHECK();
         return EGO_OK;
     }

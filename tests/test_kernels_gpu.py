@@ -65,6 +65,34 @@ def test_gemm_nt_row_range():
     assert (C[:130] == 7).all() and (C[463:] == 7).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(8292, 5120, 192), (8192, 5120, 64), (16384 + 7, 2560, 128), (65536, 768, 768)])
+def test_gemm_nt256_persistent(M, N, K):
+    """>= 640 tiles of 256 x 256 with a bf16 output run on the persistent staggered kernel: several tiles per
+    workgroup, odd / single K-step counts (stage parity carries over the tile seam), ragged last row tile."""
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    C = torch.full((M + 3, N), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16)
+    ref = A.float() @ B.float().t()
+    assert _rel(C[:M].float(), ref) < 4e-3
+    assert (C[M:] == 5).all()
+    # exact per-element check on a strided sample (catches a misplaced tile, which a norm could hide)
+    idx = torch.arange(0, M, 97, device=DEV)
+    assert (C[idx].float() - ref[idx]).abs().max().item() <= ref[idx].abs().max().item() * 2 ** -7     # one bf16 ulp
+
+
+def test_gemm_nt256_row_range():
+    M, N, K = 9000, 5120, 128                  # 36 x 20 = 720 tiles by the host bound, 33 x 20 by the device range
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    rng = torch.tensor([77, 8300], device=DEV, dtype=torch.int32)
+    ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16, m_range=rng)
+    ref = A[77:8377].float() @ B.float().t()
+    assert _rel(C[77:8377].float(), ref) < 4e-3
+    assert (C[:77] == 7).all() and (C[8377:] == 7).all()
+
+
 # ------------------------------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("M,Ni,Nj,splits", [(1000, 256, 128, 1), (4096, 768, 768, 4), (777, 2304, 768, 3), (64, 128, 128, 1),
                                              # whole-step shapes with >= 128 (tile, split) pairs run on the 256x256 staggered kernel
