@@ -245,12 +245,18 @@ __device__ __forceinline__ void bar_pinned() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Persistent: a workgroup walks tiles id, id + gridDim.x, ... as ONE pipeline.  The last K-step of a tile fetches
-// K-tile 0 of the next tile (so no tile start waits for memory), the bf16 epilogue runs in two 128-row passes through
-// the stage that K-step left free, and its global stores drain under the first K-step of the next tile.  At one
-// workgroup per CU nothing else would hide them: at K = 768 (12 K-steps per tile) the one-tile-per-workgroup form ran
-// at 820 TF/s against 1070 at long K.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant,
-// tile and K position are the scalar offset, rows past M / N read as zeros.  bf16 output only (EGO_EPI_BF16).
+// Persistent: a workgroup walks tiles id, id + gridDim.x, ... as ONE K-tile stream (stream index g runs over the
+// K-tiles of all its tiles).  A is the cold operand (activations / gradients of 100-500 MB, read from HBM), B the
+// weights (L2-resident): A gets a THREE-deep ring and is fetched two K-tiles ahead, B a two-deep ring one ahead
+// (3 x 32 + 2 x 32 KiB = all 160 KiB of LDS).  With A one tile ahead the kernel ran at 1150 TF/s on MALL-warm A and
+// 950 on cold A - the engine's case.  Per wave and K-step the four B pieces are issued before the four A pieces, so
+// "at most 4 outstanding" (vmcnt(4)) means B(g+1) and the older A(g+1) have landed while A(g+2) stays in flight.
+// The bf16 epilogue runs in two 128-row passes through the A and B stages the last K-step left free, and its stores
+// drain under the next tile.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant, tile and K
+// position are the scalar offset, rows past M / N read as zeros.  bf16 output only (EGO_EPI_BF16), K >= 128.
+constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
+constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
+
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     const int ntiles = ((M + 255) / 256) * tiles_n;
     if ((int)blockIdx.x >= ntiles) return;
     const int nt = p.K / BK;
+    const int G = gridDim.x;
 
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.A + moff * p.lda), 0, (int)(unsigned)((long)(M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
@@ -279,41 +286,72 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         a_off[j] = (unsigned)(r * (int)p.lda * 2 + c);
         b_off[j] = (unsigned)(r * (int)p.ldb * 2 + c);
     }
-    unsigned a_so = 0, b_so = 0;         // scalar byte offsets of the K-tile the next DMA fetches
-    auto dma = [&](int s, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + (wave * 4 + j) * 1024),
-                                                 16, a_off[j], (int)a_so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024),
-                                                 16, b_off[j], (int)b_so, 0, 0);
-    };
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
         row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * 256;
+    };
+    // fetch cursors: the K-tile of the stream that the next A / B DMA brings in (scalar state)
+    int idA = blockIdx.x, ktA = 0, rA, cA_unused, slotA = 0; bool moreA = true;
+    int idB = blockIdx.x, ktB = 0, rB_unused, cB, slotB = 0; bool moreB = true;
+    tile_origin(idA, rA, cA_unused);
+    tile_origin(idB, rB_unused, cB);
+    unsigned a_so = 0, b_so = 0;
+    auto cursorA = [&]() {      // set a_so for the cursor's K-tile, then advance
+        a_so = (unsigned)rA * (unsigned)(p.lda * 2) + (unsigned)(ktA * BK * 2);
+    };
+    auto advanceA = [&]() {
+        slotA = slotA == 2 ? 0 : slotA + 1;
+        if (++ktA == nt) { ktA = 0; idA += G; if (idA < ntiles) tile_origin(idA, rA, cA_unused); else moreA = false; }
+    };
+    auto cursorB = [&]() { b_so = (unsigned)cB * (unsigned)(p.ldb * 2) + (unsigned)(ktB * BK * 2); };
+    auto advanceB = [&]() {
+        slotB ^= 1;
+        if (++ktB == nt) { ktB = 0; idB += G; if (idB < ntiles) tile_origin(idB, rB_unused, cB); else moreB = false; }
+    };
+    auto dmaA = [&](int slot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (wave * 4 + j) * 1024),
+                                                 16, a_off[j], (int)a_so, 0, 0);
+    };
+    auto dmaB = [&](int slot, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
+                                                 16, b_off[j], (int)b_so, 0, 0);
     };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
     int foff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
-    const int a_base = grp * 128 * 128, b_base = T2_BYTES + wc * 64 * 128;
+    const int a_base = grp * 128 * 128, b_base = wc * 64 * 128;
 
     int id = blockIdx.x, row0, col0;
     tile_origin(id, row0, col0);
-    // prologue: K-tile 0 of the first tile by all waves
-    a_so = (unsigned)row0 * (unsigned)(p.lda * 2);
-    b_so = (unsigned)col0 * (unsigned)(p.ldb * 2);
+    // prologue: A(0), B(0), then A(1); the first two must have landed
+    cursorA();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma(0, j);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < 4; ++j) dmaA(slotA, j);
+    advanceA();
+    cursorB();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dmaB(slotB, j);
+    advanceB();
+    if (moreA) {                                // (false only for a single tile with a single K-tile)
+        cursorA();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dmaA(slotA, j);
+        advanceA();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     bar_pinned();
-    int cur = 0;                                             // stage that holds the K-tile about to be consumed
+    int curA = 0, curB = 0;                                   // ring slots of the K-tile about to be consumed
 
 #define LOAD_A(QM)                                                                                         \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
-        af[mi][ks] = *(const bf16x8*)(st + a_base + ((QM) * 4 + mi) * 2048 + foff[ks]);
+        af[mi][ks] = *(const bf16x8*)(sa + a_base + ((QM) * 4 + mi) * 2048 + foff[ks]);
 #define LOAD_B(QN)                                                                                         \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
-        bq[ni][ks] = *(const bf16x8*)(st + b_base + ((QN) * 2 + ni) * 2048 + foff[ks]);
+        bq[ni][ks] = *(const bf16x8*)(sb + b_base + ((QN) * 2 + ni) * 2048 + foff[ks]);
 #define COMPUTE(QM, QN)                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)      \
@@ -323,11 +361,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     __builtin_amdgcn_s_setprio(0);
 
     while (true) {
-        const int next_id = id + gridDim.x;
-        const bool have_next = next_id < ntiles;
-        int nrow0 = 0, ncol0 = 0;
-        if (have_next) tile_origin(next_id, nrow0, ncol0);
-
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -337,63 +370,69 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
 
         if (grp == 1) bar_pinned();                              // stagger: group 1 runs one barrier behind
         for (int kt = 0; kt < nt; ++kt) {
-            const char* st = smem + cur * S2_BYTES;
-            const int sn = cur ^ 1;
-            // what the DMA of this K-step fetches: the next K-tile of this tile, or K-tile 0 of the next tile
-            const bool more = (kt + 1 < nt) || have_next;
-            if (kt + 1 < nt) {
-                a_so = (unsigned)row0 * (unsigned)(p.lda * 2) + (unsigned)((kt + 1) * BK * 2);
-                b_so = (unsigned)col0 * (unsigned)(p.ldb * 2) + (unsigned)((kt + 1) * BK * 2);
-            } else {
-                a_so = (unsigned)nrow0 * (unsigned)(p.lda * 2);
-                b_so = (unsigned)ncol0 * (unsigned)(p.ldb * 2);
-            }
+            const char* sa = smem + curA * RA_BYTES;
+            const char* sb = smem + (3 + curB) * RA_BYTES;
+            // this K-step fetches B(g+1) into the B slot consumed in step g-1 and A(g+2) into the A slot consumed in g-1
+            // (cursors: A two K-tiles ahead of the stream, B one); scalar offsets and slots are fixed for the whole step
+            const bool fa = moreA, fb = moreB;
+            const int sA = slotA, sB = slotB;
+            if (fa) cursorA();
+            if (fb) cursorB();
             // ---- phase 0: quadrant (0,0)
             LOAD_A(0) LOAD_B(0)
-            if (more && grp == 1) { dma(sn, 0); dma(sn, 1); dma(sn, 2); }
+            if (grp == 1 && fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
             bar_pinned();
             COMPUTE(0, 0)
             bar_pinned();
             // ---- phase 1: quadrant (0,1)
             LOAD_B(1)
-            if (more) { if (grp == 1) { dma(sn, 3); } else { dma(sn, 0); dma(sn, 1); dma(sn, 2); } }
+            if (grp == 1) { if (fb) dmaB(sB, 3); if (fa) { dmaA(sA, 0); dmaA(sA, 1); } }
+            else if (fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
             bar_pinned();
             COMPUTE(0, 1)
             bar_pinned();
             // ---- phase 2: quadrant (1,1)
             LOAD_A(1)
-            if (more && grp == 0) { dma(sn, 3); }
+            if (grp == 1) { if (fa) { dmaA(sA, 2); dmaA(sA, 3); } }
+            else { if (fb) dmaB(sB, 3); if (fa) { dmaA(sA, 0); dmaA(sA, 1); } }
             bar_pinned();
             COMPUTE(1, 1)
             bar_pinned();
             // ---- phase 3: quadrant (1,0)
             LOAD_B(0)
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1: its DMA landed before slot 7 closes
+            if (grp == 0 && fa) { dmaA(sA, 2); dmaA(sA, 3); }
+            // G1: B(g+1) and the older A(g+1) landed before slot 7 closes; its 4 pieces of A(g+2) may stay in flight
+            if (grp == 1) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
             COMPUTE(1, 0)
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0: same, end of its COMPUTE(3) (slot 7)
+            if (grp == 0) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
-            cur = sn;
+            if (fa) advanceA();
+            if (fb) advanceB();
+            curA = curA == 2 ? 0 : curA + 1;
+            curB ^= 1;
         }
         if (grp == 0) bar_pinned();                              // match group 1's extra barrier: groups aligned again
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        // epilogue: stage cur ^ 1 (consumed by the last K-step) is free, stage cur already holds the next tile's K-tile 0.
-        // Two passes of 128 rows: image [128 rows][512 B]; 16-byte chunk c of row r at chunk c ^ (r & 15); every wave
-        // store instruction then writes two whole 512-byte rows.
-        char* eb = smem + (cur ^ 1) * S2_BYTES;
+        // epilogue: the A and B slots consumed by the last K-step are free (the next DMA into them is issued in the next
+        // tile's first K-step, behind the barriers below).  Two passes of 128 rows; image rows 0-63 in the A slot, 64-127
+        // in the B slot, [row][512 B], 16-byte chunk c of row r at chunk c ^ (r & 15): whole-row coalesced stores.
+        char* ea = smem + (curA == 0 ? 2 : curA - 1) * RA_BYTES;
+        char* ebb = smem + (3 + (curB ^ 1)) * RA_BYTES;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (grp == half) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int ml = i * 16 + (lane & 15);
+                    char* eb = (i < 4 ? ea : ebb) + (ml & 63) * 512;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
                         const f32x4 v = acc[i][j];
                         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2*)(eb + ml * 512 + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                        *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
                     }
                 }
             }
@@ -401,14 +440,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) {
                 const int r = ps * 16 + (tid >> 5), c = tid & 31;
-                const u32x4 v = *(const u32x4*)(eb + r * 512 + ((c ^ (r & 15)) << 4));
+                const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
                 const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
                 if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
             }
             lds_barrier();
         }
-        if (!have_next) break;
-        id = next_id; row0 = nrow0; col0 = ncol0;
+        id += G;
+        if (id >= ntiles) break;
+        tile_origin(id, row0, col0);
     }
 #undef LOAD_A
 #undef LOAD_B
@@ -771,7 +811,7 @@ void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
     if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
     if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
@@ -797,10 +837,10 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // measured on MI355X (tools/gemm_bench.py): the 256x256 kernel wins whenever the grid fills the 256 CUs for
     // about three rounds or more; very deep K with few tiles (dgrad of the logits) stays on the 128x128 kernel
     // (bf16 outputs only: with one workgroup per CU nothing hides the 8-bytes-per-element fp32 residual epilogue)
-    const bool legal256 = epi == EGO_EPI_BF16 && N % 256 == 0 && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
+    const bool legal256 = epi == EGO_EPI_BF16 && N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)));
     if (big) {
-        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT2_LDS, stream, a);
+        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
         LAUNCH_CHECK();
         return EGO_OK;
     }
