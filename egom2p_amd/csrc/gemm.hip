@@ -253,7 +253,7 @@ __device__ __forceinline__ void bar_pinned() {
 // "at most 4 outstanding" (vmcnt(4)) means B(g+1) and the older A(g+1) have landed while A(g+2) stays in flight.
 // The bf16 epilogue runs in two 128-row passes through the A and B stages the last K-step left free, and its stores
 // drain under the next tile.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant, tile and K
-// position are the scalar offset, rows past M / N read as zeros.  bf16 output only (EGO_EPI_BF16), K >= 128.
+// position are the scalar offset, rows past M / N read as zeros.  K >= 128.
 constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
 constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
 
@@ -420,31 +420,93 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         // in the B slot, [row][512 B], 16-byte chunk c of row r at chunk c ^ (r & 15): whole-row coalesced stores.
         char* ea = smem + (curA == 0 ? 2 : curA - 1) * RA_BYTES;
         char* ebb = smem + (3 + (curB ^ 1)) * RA_BYTES;
+        if (p.epi == EGO_EPI_BF16) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (grp == half) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int ml = i * 16 + (lane & 15);
-                    char* eb = (i < 4 ? ea : ebb) + (ml & 63) * 512;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
-                        const f32x4 v = acc[i][j];
-                        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+            for (int half = 0; half < 2; ++half) {
+                if (grp == half) {
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ml = i * 16 + (lane & 15);
+                        char* eb = (i < 4 ? ea : ebb) + (ml & 63) * 512;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int slot = wc * 16 + j * 4 + (lane >> 4);              // 8-byte slot (4 bf16) in the row
+                            const f32x4 v = acc[i][j];
+                            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                        }
                     }
                 }
+                lds_barrier();
+    #pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int r = ps * 16 + (tid >> 5), c = tid & 31;
+                    const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
+                    const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
+                    if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+                }
+                lds_barrier();
             }
-            lds_barrier();
+        } else {
+            // fp32 outputs (plain / + residual / + bias + residual): four passes of 64 rows, image rows 0-31 in the A slot,
+            // 32-63 in the B slot, [row][1024 B].  The residual rows of the NEXT pass are already in flight while a pass
+            // transposes and stores (the fragment registers are dead here, so two 8 x 16-byte sets fit).
+            const bool has_r = (p.epi == EGO_EPI_RESID || p.epi == EGO_EPI_BIAS_RESID);
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.epi == EGO_EPI_BIAS_RESID) {
+                const int gn = col0 + (tid & 63) * 4;
+                if (gn < p.N) { const f32x4 b = *(const f32x4*)(p.bias + gn); bb = f32x4{round_bf16(b[0]), round_bf16(b[1]), round_bf16(b[2]), round_bf16(b[3])}; }
+            }
+            // residual rows: 2 x 4 row groups per pass; each group is re-loaded for the next pass right after its use,
+            // so the loads fly under the rest of this pass and the next transpose
+            auto load_r = [&](int q, int hb, f32x4 (&rr)[4]) {
 #pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int r = ps * 16 + (tid >> 5), c = tid & 31;
-                const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
-                const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
-                if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+                for (int k = 0; k < 4; ++k) {
+                    const int gm = row0 + q * 64 + (hb * 4 + k) * 8 + (tid >> 6), gn = col0 + (tid & 63) * 4;
+                    rr[k] = (has_r && q < 4 && gm < M && gn < p.N) ? __builtin_nontemporal_load((const f32x4*)(p.R + (moff + gm) * p.ldr + gn))
+                                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            f32x4 rlo[4], rhi[4];
+            load_r(0, 0, rlo);
+            load_r(0, 1, rhi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (grp == (q >> 1)) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = (q & 1) * 4 + ii;
+                        const int ml = ii * 16 + (lane & 15);                        // row inside the 64-row pass
+                        char* eb = (ii < 2 ? ea : ebb) + (ml & 31) * 1024;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = wc * 16 + j * 4 + (lane >> 4);             // 16-byte chunk (4 fp32), 64 per row
+                            *(f32x4*)(eb + ((c ^ (ml & 15)) << 4)) = acc[i][j];
+                        }
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    f32x4 (&rr)[4] = hb == 0 ? rlo : rhi;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = (hb * 4 + k) * 8 + (tid >> 6), c = tid & 63;
+                        f32x4 v = *(const f32x4*)((hb == 0 ? ea : ebb) + (r & 31) * 1024 + ((c ^ (r & 15)) << 4));
+                        const int gm = row0 + q * 64 + r, gn = col0 + c * 4;
+                        if (gm < M && gn < p.N) {
+                            if (has_r) {
+                                const f32x4 x = rr[k];
+                                v = f32x4{x[0] + round_bf16(v[0] + bb[0]), x[1] + round_bf16(v[1] + bb[1]),
+                                          x[2] + round_bf16(v[2] + bb[2]), x[3] + round_bf16(v[3] + bb[3])};
+                            }
+                            *(f32x4*)((float*)p.C + (moff + gm) * p.ldc + gn) = v;
+                        }
+                    }
+                    if (q < 3) load_r(q + 1, hb, rr);
+                }
+                lds_barrier();
             }
-            lds_barrier();
         }
         id += G;
         if (id >= ntiles) break;
@@ -837,7 +899,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // measured on MI355X (tools/gemm_bench.py): the 256x256 kernel wins whenever the grid fills the 256 CUs for
     // about three rounds or more; very deep K with few tiles (dgrad of the logits) stays on the 128x128 kernel
     // (bf16 outputs only: with one workgroup per CU nothing hides the 8-bytes-per-element fp32 residual epilogue)
-    const bool legal256 = epi == EGO_EPI_BF16 && N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
+    const bool legal256 = N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)));
     if (big) {
         EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);

@@ -81,6 +81,27 @@ def test_gemm_nt256_persistent(M, N, K):
     assert (C[idx].float() - ref[idx]).abs().max().item() <= ref[idx].abs().max().item() * 2 ** -7     # one bf16 ulp
 
 
+def test_gemm_nt256_fp32_epilogues():
+    M, N, K = 8292, 5120, 192
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    ref = A.float() @ B.float().t()
+    C32 = torch.full((M + 2, N), 3.0, device=DEV)
+    ops.gemm_nt(A, B, C32, M, N, K, L.EPI_F32)
+    assert _rel(C32[:M], ref) < 1e-5 and (C32[M:] == 3).all()
+    R = torch.randn(M, N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(A, B, out, M, N, K, L.EPI_RESID, R=R)
+    assert _rel(out, R + _bf(ref).float()) < 2e-3
+    assert (out - R - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    ops.gemm_nt(A, B, R, M, N, K, L.EPI_RESID, R=R)                # in place on the residual stream, like the engine
+    assert torch.equal(R, out)
+    bias = torch.randn(N, device=DEV)
+    R2 = torch.randn(M, N, device=DEV)
+    ops.gemm_nt(A, B, out, M, N, K, L.EPI_BIAS_RESID, R=R2, bias=bias)
+    assert _rel(out, R2 + _bf(ref + _bf(bias).float()).float()) < 2e-3
+
+
 def test_gemm_nt256_row_range():
     M, N, K = 9000, 5120, 128                  # 36 x 20 = 720 tiles by the host bound, 33 x 20 by the device range
     A = _bf(torch.randn(M, K, device=DEV))
