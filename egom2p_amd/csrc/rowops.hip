@@ -234,28 +234,36 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ 
     const long row = (long)off + r;
     const bf16_t* lr = logits + row * ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float mx = -3.0e38f;
+    // one pass over the row (128 KB at V = 64000): running maximum and rescaled sum per thread, 4 loads in flight
+    float mx = -3.0e38f, s = 0.f;
     const int vc = V >> 3;
-    for (int c = threadIdx.x; c < vc; c += 256) {
-        const u32x4 a = *(const u32x4*)(lr + c * 8);
+    auto fold = [&](const u32x4& a) {
+        float x[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(bf16_to_f32(a[e] & 0xffff), bf16_to_f32(a[e] >> 16)));
+        for (int e = 0; e < 4; ++e) { x[2 * e] = bf16_to_f32(a[e] & 0xffff); x[2 * e + 1] = bf16_to_f32(a[e] >> 16); }
+        float cm = x[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) cm = fmaxf(cm, x[e]);
+        if (cm > mx) { s *= __expf(mx - cm); mx = cm; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += __expf(x[e] - mx);
+    };
+    int c = threadIdx.x;
+    for (; c + 768 < vc; c += 1024) {
+        const u32x4 a0 = *(const u32x4*)(lr + c * 8), a1 = *(const u32x4*)(lr + (c + 256) * 8);
+        const u32x4 a2 = *(const u32x4*)(lr + (c + 512) * 8), a3 = *(const u32x4*)(lr + (c + 768) * 8);
+        fold(a0); fold(a1); fold(a2); fold(a3);
     }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
+    for (; c < vc; c += 256) fold(*(const u32x4*)(lr + c * 8));
+    // combine (max, sum) pairs: wave, then the four waves
+    const float wm = wave_max(mx);
+    s = wave_sum(s * __expf(mx - wm));
+    if (lane == 0) { red[wave] = wm; red[4 + wave] = s; }
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float s = 0.f;
-    for (int c = threadIdx.x; c < vc; c += 256) {
-        const u32x4 a = *(const u32x4*)(lr + c * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += __expf(bf16_to_f32(a[e] & 0xffff) - mx) + __expf(bf16_to_f32(a[e] >> 16) - mx);
-    }
-    s = wave_sum(s);
-    if (lane == 0) red[4 + wave] = s;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        const float lse = mx + __logf(red[4] + red[5] + red[6] + red[7]);
+        const float tot = red[4] * __expf(red[0] - mx) + red[5] * __expf(red[1] - mx) + red[6] * __expf(red[2] - mx) + red[7] * __expf(red[3] - mx);
+        const float lse = mx + __logf(tot);
         lse_out[row] = lse;
         nll_out[row] = lse - bf16_to_f32(lr[targets[row]]);
     }
