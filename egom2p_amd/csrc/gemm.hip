@@ -895,12 +895,12 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     ensure_attrs();
     NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-    // the 256x256 kernel runs one workgroup per CU: take it when the grid fills whole rounds of 256 reasonably well
-    // measured on MI355X (tools/gemm_bench.py): the 256x256 kernel wins whenever the grid fills the 256 CUs for
-    // about three rounds or more; very deep K with few tiles (dgrad of the logits) stays on the 128x128 kernel
-    // (bf16 outputs only: with one workgroup per CU nothing hides the 8-bytes-per-element fp32 residual epilogue)
+    // The persistent 256x256 kernel runs one workgroup per CU.  Measured on MI355X (tools/gemm_bench.py, EGO_GEMM_NT256=2
+    // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
+    // partly filled single round on (dgrad of the logits: 1030-1110 vs 800-950 TF/s); few tiles with K = 768 and the
+    // residual epilogue stay on the 128x128 kernel (two workgroups per CU hide each other's epilogue).
     const bool legal256 = N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
-    const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && tiles256 >= 640 && !(K >= 8192 && tiles256 < 1024)));
+    const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
     if (big) {
         EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
         LAUNCH_CHECK();
