@@ -41,6 +41,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -36,7 +36,9 @@ struct NTArgs {
     const float* bias;
     const int* m_range;
     int M, N, K, epi;
+    const bf16_t* X; long ldx;      // EPI_SWIGLU_BWD: the saved SwiGLU pre-activations ab [M, 2N]
 };
+constexpr int EPI_SWIGLU_BWD = 100;   // internal: C(bf16)[M, 2N] = SwiGLU backward of (acc rounded to bf16) against X
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel, persistent.  Each workgroup walks a strided list of 128x128 output tiles; the K loop runs
@@ -257,6 +259,7 @@ __device__ __forceinline__ void bar_pinned() {
 constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
 constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
 
+template <int EK>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward (separate register allocations)
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         // in the B slot, [row][512 B], 16-byte chunk c of row r at chunk c ^ (r & 15): whole-row coalesced stores.
         char* ea = smem + (curA == 0 ? 2 : curA - 1) * RA_BYTES;
         char* ebb = smem + (3 + (curB ^ 1)) * RA_BYTES;
-        if (p.epi == EGO_EPI_BF16) {
+        if constexpr (EK == 0) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (grp == half) {
@@ -444,6 +447,82 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                     const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
                     const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
                     if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+                }
+                lds_barrier();
+            }
+        } else if constexpr (EK == 2) {
+            // The tile is dh = dY W2 (never stored): da = dh b s (1 + a (1 - s)), db = dh a s with s = sigmoid(a), written
+            // to dab[:, n] and dab[:, N + n] (ego_swiglu_bwd's arithmetic on the bf16-rounded dh, bit for bit).  Two passes
+            // of 128 rows like the bf16 epilogue; a and b rows are fetched two groups ahead of their use.
+            const bf16_t* Xb = p.X + moff * p.ldx;
+            bf16_t* Yb = (bf16_t*)p.C + moff * p.ldc;
+            // groups of 2 row slices (8 groups per tile, 4 per pass), two groups in flight
+            auto load_ab = [&](int g, u32x4 (&av)[2], u32x4 (&bv)[2]) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int gm = row0 + (g >> 2) * 128 + ((g & 3) * 2 + k) * 16 + (tid >> 5), gn = col0 + (tid & 31) * 8;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    const bool ok = g < 8 && gm < M;
+                    av[k] = ok ? __builtin_nontemporal_load((const u32x4*)(Xb + (long)gm * p.ldx + gn)) : z;
+                    bv[k] = ok ? __builtin_nontemporal_load((const u32x4*)(Xb + (long)gm * p.ldx + p.N + gn)) : z;
+                }
+            };
+            auto process = [&](int g, const u32x4 (&av)[2], const u32x4 (&bv)[2]) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int ps = (g & 3) * 2 + k;
+                    const int r = ps * 16 + (tid >> 5), c = tid & 31;
+                    const u32x4 gq = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
+                    const int gm = row0 + (g >> 2) * 128 + r, gn = col0 + c * 8;
+                    u32x4 oa, ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a2[2] = {bf16_to_f32(av[k][e] & 0xffff), bf16_to_f32(av[k][e] >> 16)};
+                        const float b2[2] = {bf16_to_f32(bv[k][e] & 0xffff), bf16_to_f32(bv[k][e] >> 16)};
+                        const float g2[2] = {bf16_to_f32(gq[e] & 0xffff), bf16_to_f32(gq[e] >> 16)};
+                        float da[2], db[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const float sg = sigmoidf_(a2[t]);
+                            da[t] = g2[t] * b2[t] * sg * (1.f + a2[t] * (1.f - sg));
+                            db[t] = g2[t] * a2[t] * sg;
+                        }
+                        oa[e] = pack_bf16x2(da[0], da[1]);
+                        ob[e] = pack_bf16x2(db[0], db[1]);
+                    }
+                    if (gm < M) {
+                        __builtin_nontemporal_store(oa, (u32x4*)(Yb + (long)gm * p.ldc + gn));
+                        __builtin_nontemporal_store(ob, (u32x4*)(Yb + (long)gm * p.ldc + p.N + gn));
+                    }
+                }
+            };
+            u32x4 a0[2], b0[2], a1[2], b1[2];
+            load_ab(0, a0, b0);
+            load_ab(1, a1, b1);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (grp == half) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ml = i * 16 + (lane & 15);
+                        char* eb = (i < 4 ? ea : ebb) + (ml & 63) * 512;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int slot = wc * 16 + j * 4 + (lane >> 4);
+                            const f32x4 v = acc[i][j];
+                            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                        }
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int gg = 0; gg < 4; gg += 2) {
+                    const int g = half * 4 + gg;
+                    process(g, a0, b0);
+                    load_ab(g + 2, a0, b0);
+                    process(g + 1, a1, b1);
+                    load_ab(g + 3, a1, b1);
                 }
                 lds_barrier();
             }
@@ -873,7 +952,9 @@ void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
     if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
     if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
@@ -893,7 +974,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
-    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi};
+    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     // The persistent 256x256 kernel runs one workgroup per CU.  Measured on MI355X (tools/gemm_bench.py, EGO_GEMM_NT256=2
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
@@ -902,12 +983,28 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     const bool legal256 = N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
     if (big) {
-        EGO_LAUNCH(gemm_nt256_kernel, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
+        if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+        else { EGO_LAUNCH(gemm_nt256_kernel<1>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
         LAUNCH_CHECK();
         return EGO_OK;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), NT_LDS, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, const void* ab, void* dab, long ld_ab,
+                                      int M, int F, int K, hipStream_t stream) {
+    if (M <= 0) return EGO_OK;
+    // only the persistent 256x256 kernel carries this epilogue; the caller falls back to gemm + ego_swiglu_bwd otherwise
+    if (F % 256 || K % BK || K < 2 * BK || ldy % 8 || ldw % 8 || ld_ab % 8 || ld_ab < 2L * F) return EGO_ERR_ARG;
+    if ((long)M * ldy * 2 >= 0xfff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
+    ensure_attrs();
+    NTArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)W2t, ldw, dab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_BWD,
+             (const bf16_t*)ab, ld_ab};
+    const int tiles256 = ((M + 255) / 256) * (F / 256);
+    EGO_LAUNCH(gemm_nt256_kernel<2>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -140,7 +140,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // SwiGLU gate.  ab[rows, 2F]: a = cols [0,F), b = cols [F,2F).  h = bf16(bf16(silu(a)) * b)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ ab, bf16_t* __restrict__ hout, long rows, int F) {
     const int fc = F >> 3;                      // 8-element chunks per row

@@ -505,8 +505,14 @@ class Engine:
         """residual-stream gradient through x + fc2(swiglu(fc13(LN2(x)))); xin = LN2 input (saved)."""
         Fp = self.Fp
         dh, dab, dln = self.t_f, self.t_2f, self.t_d
-        self._lin_bwd(f"{pre}.mlp.fc2.weight", dres_b, w["h"], dh, rows)
-        ops.swiglu_bwd(w["ab"], dh, dab, rows, Fp)
+        l2 = self.lin[f"{pre}.mlp.fc2.weight"]
+        if ops.swiglu_bwd_fusable(Fp, l2.out_f) and rows >= 4096:
+            # fc2 dgrad and the gate backward in one launch (dh never reaches HBM), then the fc2 wgrad
+            ops.gemm_nt_swiglu_bwd(dres_b, l2.wt, w["ab"], dab, rows, Fp, l2.out_f, ldy=dres_b.shape[-1], ldw=l2.out_f)
+            self._wgrad(l2.g, dres_b, w["h"], l2.out_f, l2.in_f, rows, ldp=dres_b.shape[-1], ldq=w["h"].shape[-1])
+        else:
+            self._lin_bwd(f"{pre}.mlp.fc2.weight", dres_b, w["h"], dh, rows)
+            ops.swiglu_bwd(w["ab"], dh, dab, rows, Fp)
         self._lin_bwd(f"{pre}.mlp.fc13", dab, w["ln2"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],

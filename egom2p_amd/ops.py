@@ -96,6 +96,20 @@ def swiglu_fwd(ab, h, rows, F):
     check(L.load().ego_swiglu_fwd(_p(ab), _p(h), rows, F, _stream()), "ego_swiglu_fwd")
 
 
+def swiglu_bwd_fusable(F, K):
+    """shapes the fused fc2-dgrad + gate-backward launch accepts (else: gemm_nt + swiglu_bwd)"""
+    return F % 256 == 0 and K % 64 == 0 and K >= 128 and os.environ.get("EGOM2P_FUSE_SWIGLU_BWD", "1") != "0"
+
+
+def gemm_nt_swiglu_bwd(dY, W2t, ab, dab, M, F, K, ldy=None, ldw=None):
+    """dab[M,2F] = swiglu_bwd(ab, dY[M,K] @ W2t[F,K]^T) without materialising dh."""
+    _need_cuda(dY)
+    ldy = dY.stride(-2) if ldy is None else ldy
+    ldw = W2t.stride(-2) if ldw is None else ldw
+    check(L.load().ego_gemm_nt_swiglu_bwd(_p(dY), ldy, _p(W2t), ldw, _p(ab), _p(dab), ab.stride(-2), M, F, K, _stream()),
+          "ego_gemm_nt_swiglu_bwd")
+
+
 def swiglu_bwd(ab, dh, dab, rows, F):
     check(L.load().ego_swiglu_bwd(_p(ab), _p(dh), _p(dab), rows, F, _stream()), "ego_swiglu_bwd")
 

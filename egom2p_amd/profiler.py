@@ -49,6 +49,9 @@ class KernelTimer:
             m = min(M, rows_of(m_range, M))
             return 2.0 * m * N * K, 2.0 * (m * K + N * K) + (2.0 if epi == 0 else 8.0) * m * N
 
+        def c_gemm_nt_swiglu_bwd(dY, W2t, ab, dab, M, F, K, **kw):
+            return 2.0 * M * F * K, 2.0 * (M * K + F * K) + 8.0 * M * F       # ab read + dab write, 2 x 2 B x 2F each
+
         def c_gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_range=None, **kw):
             m = min(M, rows_of(m_range, M))
             return 2.0 * m * Ni * Nj, 2.0 * m * (Ni + Nj) + 8.0 * Ni * Nj
@@ -96,7 +99,7 @@ class KernelTimer:
             return 0.0, n * V * 4.0
 
         table = {
-            "gemm_nt": c_gemm_nt, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
+            "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
             "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
             "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
         }

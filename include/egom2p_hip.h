@@ -129,6 +129,13 @@ int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_
 /* SwiGLU gate on the fused fc1||fc3 output ab[rows, 2F] (GatedMlp, egom2p_utils.py:167-169). */
 int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream);
 int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long rows, int F, hipStream_t stream);
+/* The fc2 input gradient and the gate backward in one launch: dh = dY[M,K] @ W2t[F,K]^T is formed tile by tile in
+ * the GEMM and consumed by its epilogue (autograd of GatedMlp.forward, egom2p_utils.py:167-169, through fc2 and the
+ * SiLU gate); dab[M,2F] receives exactly what ego_gemm_nt_bf16(EPI_BF16) + ego_swiglu_bwd would write, without the
+ * 2 x M x F x 2 bytes of dh going to HBM and back.  F % 256 == 0, K % 64 == 0, K >= 128 (EGO_ERR_ARG otherwise: the
+ * caller then uses the two-call form). */
+int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, const void* ab, void* dab, long ld_ab,
+                           int M, int F, int K, hipStream_t stream);
 
 /* ---- loss head ------------------------------------------------------------------------------- */
 

@@ -102,6 +102,22 @@ def test_gemm_nt256_fp32_epilogues():
     assert _rel(out, R2 + _bf(ref + _bf(bias).float()).float()) < 2e-3
 
 
+def test_gemm_nt_swiglu_bwd_fused_equals_two_calls():
+    """fc2 dgrad + gate backward in one launch writes bit for bit what gemm_nt(EPI_BF16) + swiglu_bwd write"""
+    for M, F, K in [(4200, 2048, 768), (8192 + 9, 512, 128)]:
+        dY = _bf(torch.randn(M, K, device=DEV))
+        W2t = _bf(torch.randn(F, K, device=DEV) * 0.05)          # fc2 weight transposed: [F, K]
+        ab = _bf(torch.randn(M, 2 * F, device=DEV) * 2)
+        dh = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+        ref = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(dY, W2t, dh, M, F, K, L.EPI_BF16)
+        ops.swiglu_bwd(ab, dh, ref, M, F)
+        out = torch.full((M + 1, 2 * F), 9.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt_swiglu_bwd(dY, W2t, ab, out, M, F, K)
+        assert torch.equal(out[:M], ref)
+        assert (out[M:] == 9).all()
+
+
 def test_gemm_nt256_row_range():
     M, N, K = 9000, 5120, 128                  # 36 x 20 = 720 tiles by the host bound, 33 x 20 by the device range
     A = _bf(torch.randn(M, K, device=DEV))
