@@ -277,8 +277,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     const int nt = p.K / BK;
     const int G = gridDim.x;
 
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.A + moff * p.lda), 0, (int)(unsigned)((long)(M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+    // A: one descriptor per 256-row tile (based at the tile's first row, sized to its valid rows), so the 32-bit buffer
+    // offsets never see more than 256 rows - activations / logit gradients larger than 4 GiB are fine
+    auto a_rsrc = [&](int row0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (moff + row0) * p.lda), 0,
+                                                 (int)(unsigned)((long)(min(256, M - row0) - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+    };
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.B, 0, (int)(unsigned)((long)(p.N - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
     // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
@@ -299,12 +303,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     tile_origin(idA, rA, cA_unused);
     tile_origin(idB, rB_unused, cB);
     unsigned a_so = 0, b_so = 0;
-    auto cursorA = [&]() {      // set a_so for the cursor's K-tile, then advance
-        a_so = (unsigned)rA * (unsigned)(p.lda * 2) + (unsigned)(ktA * BK * 2);
-    };
+    __amdgpu_buffer_rsrc_t ars = a_rsrc(rA);
+    auto cursorA = [&]() { a_so = (unsigned)(ktA * BK * 2); };      // scalar offset of the cursor's K-tile inside its tile rows
     auto advanceA = [&]() {
         slotA = slotA == 2 ? 0 : slotA + 1;
-        if (++ktA == nt) { ktA = 0; idA += G; if (idA < ntiles) tile_origin(idA, rA, cA_unused); else moreA = false; }
+        if (++ktA == nt) {
+            ktA = 0; idA += G;
+            if (idA < ntiles) { tile_origin(idA, rA, cA_unused); ars = a_rsrc(rA); } else moreA = false;
+        }
     };
     auto cursorB = [&]() { b_so = (unsigned)cB * (unsigned)(p.ldb * 2) + (unsigned)(ktB * BK * 2); };
     auto advanceB = [&]() {
@@ -806,14 +812,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     const int per = (nsteps + p.splits - 1) / p.splits;
     const int st0 = split * per, st1 = min(nsteps, st0 + per);
 
-    // LDS-DMA by buffer loads: each operand panel [M rows][256 columns] is a raw buffer that ends with row M-1, so the
-    // rows of a last partial 64-row step read as zeros (they must contribute nothing - no tail path); the lane's piece
-    // offsets are loop-invariant, the step's position is the scalar offset.  Wave instruction (wave*4 + j) fills tile
-    // rows 2(wave*4+j), +1 (512 B each); 32-byte chunk swizzle on the source.  (The launcher guarantees < 4 GiB spans.)
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.P + moff * p.ldp + i0), 0, (int)(unsigned)((long)(M - 1) * p.ldp * 2 + 512), 0x00020000);
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.Q + moff * p.ldq + j0), 0, (int)(unsigned)((long)(M - 1) * p.ldq * 2 + 512), 0x00020000);
+    // LDS-DMA by buffer loads.  Every 64-row step gets its own pair of descriptors, based at the step's first row and
+    // sized to its valid rows: the rows of a last partial step read as zeros (they must contribute nothing - no tail
+    // path), and the 32-bit buffer offsets only ever span 64 rows (operands beyond 4 GiB, e.g. the logit gradients, are
+    // fine).  The lane's piece offsets are loop-invariant.  Wave instruction (wave*4 + j) fills tile rows 2(wave*4+j), +1
+    // (512 B each); 32-byte chunk swizzle on the source.
+    const bf16_t* Pb = p.P + moff * p.ldp + i0;
+    const bf16_t* Qb = p.Q + moff * p.ldq + j0;
     unsigned p_off[4], q_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -823,10 +828,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
         q_off[j] = (unsigned)(r * p.ldq * 2 + c * 16);
     }
     auto dma = [&](int s, int m0, int j) {
+        const int rows = min(BK, M - m0);
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Pb + (long)m0 * p.ldp), 0, (int)(unsigned)((long)(rows - 1) * p.ldp * 2 + 512), 0x00020000);
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Qb + (long)m0 * p.ldq), 0, (int)(unsigned)((long)(rows - 1) * p.ldq * 2 + 512), 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + (wave * 4 + j) * 1024),
-                                                 16, p_off[j], (int)((unsigned)m0 * (unsigned)(p.ldp * 2)), 0, 0);
+                                                 16, p_off[j], 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024),
-                                                 16, q_off[j], (int)((unsigned)m0 * (unsigned)(p.ldq * 2)), 0, 0);
+                                                 16, q_off[j], 0, 0, 0);
     };
     // transposed-read addresses (stage 0): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16
     // block; 16-column block ci of row r sits at 32-byte chunk ci ^ tn_f(r), and tn_f is the same for r0, r0+4, r0+32
@@ -980,7 +990,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
     // partly filled single round on (dgrad of the logits: 1030-1110 vs 800-950 TF/s); few tiles with K = 768 and the
     // residual epilogue stay on the 128x128 kernel (two workgroups per CU hide each other's epilogue).
-    const bool legal256 = N % 256 == 0 && K >= 2 * BK && (long)M * lda * 2 < 0xfff00000L && (long)N * ldb * 2 < 0xfff00000L;
+    const bool legal256 = N % 256 == 0 && K >= 2 * BK && 256L * lda * 2 < 0x7ff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
     if (big) {
         if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
@@ -999,7 +1009,7 @@ extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t,
     if (M <= 0) return EGO_OK;
     // only the persistent 256x256 kernel carries this epilogue; the caller falls back to gemm + ego_swiglu_bwd otherwise
     if (F % 256 || K % BK || K < 2 * BK || ldy % 8 || ldw % 8 || ld_ab % 8 || ld_ab < 2L * F) return EGO_ERR_ARG;
-    if ((long)M * ldy * 2 >= 0xfff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
+    if (256L * ldy * 2 >= 0x7ff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)W2t, ldw, dab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_BWD,
              (const bf16_t*)ab, ld_ab};
@@ -1018,9 +1028,8 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     if (!C1) { split_row = Ni; rows1 = 0; }
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
-    // 256x256 staggered kernel, one workgroup per CU: operand spans must fit the 32-bit buffer offsets
-    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && M > 0 &&
-                          (long)M * ldp * 2 < 0xfff00000L && (long)M * ldq * 2 < 0xfff00000L;
+    // 256x256 staggered kernel, one workgroup per CU
+    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && M > 0 && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
     const int tiles256 = (Ni / 256) * (Nj / 256);
     if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
         EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT2_LDS, stream, a);

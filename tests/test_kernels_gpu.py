@@ -186,6 +186,28 @@ def test_gemm_tn256_range_ragged_and_split_rows():
     assert _rel(G, ref2) < 1e-5
 
 
+def test_gemms_on_operands_beyond_4gib():
+    """the logit-gradient operand of a large micro-batch exceeds 4 GiB: the 256-kernels re-base their buffer
+    descriptors per tile / per step, so 32-bit buffer offsets never limit the operand size"""
+    M, V, D = 40000, 64000, 256
+    A = torch.empty(M, V, device=DEV, dtype=torch.bfloat16)            # 5.1 GB
+    for r in range(0, M, 4000):
+        A[r:r + 4000] = _bf(torch.randn(4000, V, device=DEV))
+    W = _bf(torch.randn(D, V, device=DEV) * 0.02)
+    C = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, C, M, D, V, L.EPI_BF16)                          # dgrad of the logits: [M, V] x [D, V]^T
+    for lo, hi in ((0, 64), (33500, 33700), (M - 100, M)):             # 33554 rows = 4 GiB
+        ref = A[lo:hi].float() @ W.float().t()
+        assert _rel(C[lo:hi].float(), ref) < 4e-3, (lo, hi)
+    X = _bf(torch.randn(M, D, device=DEV))
+    G = torch.zeros(V, D, device=DEV)
+    ops.gemm_tn(A, X, G, V, D, M)                                      # wgrad of the table: A^T X
+    for lo, hi in ((0, 256), (63744, 64000)):
+        ref = A[:, lo:hi].float().t() @ X.float()
+        assert _rel(G[lo:hi], ref) < 1e-4, (lo, hi)
+    del A
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, ks, ke, scale):
     """fp32 reference with the reference's masked_fill(-max) semantics. q:(B,H,Nq,64) k,v:(B,H,Nk,64); ks,ke:(B,Nq)."""
