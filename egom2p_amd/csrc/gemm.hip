@@ -868,44 +868,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
         pf[mi][0] = tr_pair<0>(pa[(QM) * 4 + mi] + (SO));                                                \
         pf[mi][1] = tr_pair<32 * 512>(pa[(QM) * 4 + mi] + (SO));                                         \
     }
-#define TLOAD_Q(QN, SO)                                                                                  \
+#define TLOAD_Q(QV, QN, SO)                                                                              \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                   \
-        qf[ni][0] = tr_pair<0>(qa[(QN) * 2 + ni] + (SO));                                                \
-        qf[ni][1] = tr_pair<32 * 512>(qa[(QN) * 2 + ni] + (SO));                                         \
+        QV[ni][0] = tr_pair<0>(qa[(QN) * 2 + ni] + (SO));                                                \
+        QV[ni][1] = tr_pair<32 * 512>(qa[(QN) * 2 + ni] + (SO));                                         \
     }
-#define TCOMPUTE(QM, QN)                                                                                 \
+#define TCOMPUTE(QV, QM, QN)                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)    \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                 \
             acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
-                qf[ni][ks], pf[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                     \
+                QV[ni][ks], pf[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                     \
     __builtin_amdgcn_s_setprio(0);
 
+        // the Q fragments of column half 0 serve quadrants (0,0) and (1,0): they stay in registers (q0) from phase 0 to
+        // phase 3 instead of being read from LDS twice - the transposed reads are the scarce resource of this kernel
+        bf16x8 q0[2][2];
         for (int st = st0; st < st1; ++st) {
             const unsigned so = ((st - st0) & 1) * S2_BYTES;
             const int sn = ((st - st0) & 1) ^ 1, mn = (st + 1) * BK;
             const bool more = st + 1 < st1;
-            TLOAD_P(0, so) TLOAD_Q(0, so)
+            TLOAD_P(0, so) TLOAD_Q(q0, 0, so)
             if (more && grp == 1) { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); }
             bar_pinned();
-            TCOMPUTE(0, 0)
+            TCOMPUTE(q0, 0, 0)
             bar_pinned();
-            TLOAD_Q(1, so)
+            TLOAD_Q(qf, 1, so)
             if (more) { if (grp == 1) { dma(sn, mn, 3); } else { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); } }
             bar_pinned();
-            TCOMPUTE(0, 1)
+            TCOMPUTE(qf, 0, 1)
             bar_pinned();
             TLOAD_P(1, so)
             if (more && grp == 0) { dma(sn, mn, 3); }
             bar_pinned();
-            TCOMPUTE(1, 1)
+            TCOMPUTE(qf, 1, 1)
             bar_pinned();
-            TLOAD_Q(0, so)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bar_pinned();
-            TCOMPUTE(1, 0)
+            TCOMPUTE(q0, 1, 0)
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bar_pinned();
         }
