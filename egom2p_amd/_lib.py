@@ -42,6 +42,7 @@ class EmbedBwdDesc(C.Structure):
 
 _SIGS = {
     "ego_abi_version": [],
+    "ego_gemm_kernel_mode": [i32, i32],
     "ego_compact": [C.POINTER(CompactDesc), i32, vp],
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
     "ego_embed_bwd": [C.POINTER(EmbedBwdDesc), vp],

@@ -977,6 +977,16 @@ void ensure_attrs() {
 
 }  // namespace
 
+extern "C" int ego_gemm_kernel_mode(int nt256, int tn256) {
+    // which tile family the two GEMM entries may pick: 1 = by shape (default), 0 = 128x128 kernels only, 2 = 256x256
+    // wherever legal.  Results are the same up to fp32 summation order; used by the full-size cross-check test.
+    if (nt256 < 0 || nt256 > 2 || tn256 < 0 || tn256 > 2) return EGO_ERR_ARG;
+    ensure_attrs();
+    g_nt256 = nt256;
+    g_tn256 = tn256;
+    return EGO_OK;
+}
+
 extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                                 const float* R, long ldr, const float* bias, const int* m_range,
                                 int M, int N, int K, int epi, hipStream_t stream) {

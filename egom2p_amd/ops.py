@@ -68,6 +68,12 @@ def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_ra
                                     M, splits, _p(slab), _stream()), "ego_gemm_tn_bf16")
 
 
+def gemm_kernel_mode(nt256=1, tn256=1):
+    """1 = tile family by shape (default), 0 = 128x128 kernels only, 2 = 256x256 wherever legal"""
+    check(L.load().ego_gemm_kernel_mode(nt256, tn256), "ego_gemm_kernel_mode")
+    os.environ["EGO_GEMM_TN256"] = str(tn256)          # tn_splits mirrors the launcher's choice
+
+
 def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, wgs128=512, wgs256=256):
     """Split-K factor for `gemm_tn`: one full round of workgroups and no more.  Large whole-step shapes run on the
     256x256 kernel (1 workgroup per CU), the rest on the 128x128 kernel (2 per CU); mirrors the launcher's choice."""

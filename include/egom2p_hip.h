@@ -30,6 +30,9 @@ extern "C" {
 #define EGO_EPI_BIAS_RESID 3  /* C(f32)  = R(f32) + bf16(acc + bias) context projection   */
 
 int ego_abi_version(void);
+/* Tile family the GEMM entries may pick (1 = by shape, 0 = 128x128 kernels only, 2 = 256x256 wherever legal); same
+ * results up to fp32 summation order.  No reference counterpart: test / tuning hook (tests/test_engine_gpu.py). */
+int ego_gemm_kernel_mode(int nt256, int tn256);
 
 /* ---- front end ------------------------------------------------------------------------------- */
 
