@@ -58,6 +58,7 @@ _SIGS = {
     "ego_swiglu_fwd": [vp, vp, i64, i32, vp],
     "ego_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
     "ego_gemm_nt_swiglu_bwd": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp],
+    "ego_gemm_nt_swiglu_fwd": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "ego_ce_fwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp],
     "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp],
     "ego_loss_finalize": [vp, vp, i32, vp, vp],

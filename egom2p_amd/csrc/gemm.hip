@@ -37,7 +37,9 @@ struct NTArgs {
     const int* m_range;
     int M, N, K, epi;
     const bf16_t* X; long ldx;      // EPI_SWIGLU_BWD: the saved SwiGLU pre-activations ab [M, 2N]
+    bf16_t* H; long ldh;            // EPI_SWIGLU_FWD: the gate output h [M, N]
 };
+constexpr int EPI_SWIGLU_FWD = 101;   // internal: C = ab [M, 2N] and H = bf16(bf16(silu(a)) * b) [M, N] from one 256 x (128 a + 128 b) tile
 constexpr int EPI_SWIGLU_BWD = 100;   // internal: C(bf16)[M, 2N] = SwiGLU backward of (acc rounded to bf16) against X
 
 // ---------------------------------------------------------------------------------------------
@@ -259,7 +261,7 @@ __device__ __forceinline__ void bar_pinned() {
 constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
 constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
 
-template <int EK>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward (separate register allocations)
+template <int EK>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward, 3 fused SwiGLU forward (separate register allocations)
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -270,7 +272,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     long moff = 0;
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
     if (M <= 0) return;
-    const int tiles_n = (p.N + 255) / 256;
+    // EK 3: a tile is 128 columns of the a half plus the matching 128 columns of the b half of fc1||fc3 (p.N = F)
+    const int tiles_n = EK == 3 ? p.N / 128 : (p.N + 255) / 256;
+    const int tile_w = EK == 3 ? 128 : 256;
     // M may come from the device (row range of one modality): spread the tiles that really exist over the XCDs
     const int ntiles = ((M + 255) / 256) * tiles_n;
     if ((int)blockIdx.x >= ntiles) return;
@@ -284,18 +288,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                                                  (int)(unsigned)((long)(min(256, M - row0) - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.B, 0, (int)(unsigned)((long)(p.N - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
+        (void*)p.B, 0, (int)(unsigned)((long)((EK == 3 ? 2 * p.N : p.N) - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
     // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
     unsigned a_off[4], b_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * (wave * 4 + j) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
         a_off[j] = (unsigned)(r * (int)p.lda * 2 + c);
-        b_off[j] = (unsigned)(r * (int)p.ldb * 2 + c);
+        b_off[j] = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * 2 + c);
     }
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
-        row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * 256;
+        row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * tile_w;
     };
     // fetch cursors: the K-tile of the stream that the next A / B DMA brings in (scalar state)
     int idA = blockIdx.x, ktA = 0, rA, cA_unused, slotA = 0; bool moreA = true;
@@ -453,6 +457,50 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                     const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
                     const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
                     if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+                }
+                lds_barrier();
+            }
+        } else if constexpr (EK == 3) {
+            // tile columns 0-127 are a[:, col0 ..], columns 128-255 are b[:, col0 ..]: both halves of ab are stored (the
+            // backward needs them) together with h = bf16(bf16(silu(a)) * b) (ego_swiglu_fwd's arithmetic on the bf16 ab)
+            bf16_t* Cb = (bf16_t*)p.C + moff * p.ldc;
+            bf16_t* Hb = p.H + moff * p.ldh;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (grp == half) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ml = i * 16 + (lane & 15);
+                        char* eb = (i < 4 ? ea : ebb) + (ml & 63) * 512;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int slot = wc * 16 + j * 4 + (lane >> 4);
+                            const f32x4 v = acc[i][j];
+                            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                        }
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 32 + (tid >> 4), c = tid & 15;
+                    const char* rowp = (ps < 2 ? ea : ebb) + (r & 63) * 512;
+                    const u32x4 av = *(const u32x4*)(rowp + ((c ^ (r & 15)) << 4));
+                    const u32x4 bv = *(const u32x4*)(rowp + (((c + 16) ^ (r & 15)) << 4));
+                    u32x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = bf16_to_f32(av[e] & 0xffff), a1 = bf16_to_f32(av[e] >> 16);
+                        const float b0 = bf16_to_f32(bv[e] & 0xffff), b1 = bf16_to_f32(bv[e] >> 16);
+                        hv[e] = pack_bf16x2(round_bf16(a0 * sigmoidf_(a0)) * b0, round_bf16(a1 * sigmoidf_(a1)) * b1);
+                    }
+                    const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
+                    if (gm < M) {
+                        __builtin_nontemporal_store(av, (u32x4*)(Cb + (long)gm * p.ldc + gn));
+                        __builtin_nontemporal_store(bv, (u32x4*)(Cb + (long)gm * p.ldc + p.N + gn));
+                        __builtin_nontemporal_store(hv, (u32x4*)(Hb + (long)gm * p.ldh + gn));
+                    }
                 }
                 lds_barrier();
             }
@@ -967,6 +1015,7 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
     if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
     if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
@@ -996,7 +1045,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
-    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0};
+    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0, nullptr, 0};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     // The persistent 256x256 kernel runs one workgroup per CU.  Measured on MI355X (tools/gemm_bench.py, EGO_GEMM_NT256=2
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
@@ -1016,6 +1065,21 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     return EGO_OK;
 }
 
+extern "C" int ego_gemm_nt_swiglu_fwd(const void* X, long ldx, const void* W13, long ldw, void* ab, long ld_ab, void* h, long ld_h,
+                                      int M, int F, int K, hipStream_t stream) {
+    if (M <= 0) return EGO_OK;
+    // only the persistent 256x256 kernel carries this epilogue; the caller falls back to gemm + ego_swiglu_fwd otherwise
+    if (F % 128 || K % BK || K < 2 * BK || ldx % 8 || ldw % 8 || ld_ab % 8 || ld_h % 8 || ld_ab < 2L * F || ld_h < F) return EGO_ERR_ARG;
+    if (256L * ldx * 2 >= 0x7ff00000L || 2L * F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
+    ensure_attrs();
+    NTArgs a{(const bf16_t*)X, ldx, (const bf16_t*)W13, ldw, ab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_FWD,
+             nullptr, 0, (bf16_t*)h, ld_h};
+    const int tiles = ((M + 255) / 256) * (F / 128);
+    EGO_LAUNCH(gemm_nt256_kernel<3>, dim3(tiles < 256 ? tiles : 256), dim3(512), NT3_LDS, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
 extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, const void* ab, void* dab, long ld_ab,
                                       int M, int F, int K, hipStream_t stream) {
     if (M <= 0) return EGO_OK;
@@ -1024,7 +1088,7 @@ extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t,
     if (256L * ldy * 2 >= 0x7ff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)W2t, ldw, dab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_BWD,
-             (const bf16_t*)ab, ld_ab};
+             (const bf16_t*)ab, ld_ab, nullptr, 0};
     const int tiles256 = ((M + 255) / 256) * (F / 256);
     EGO_LAUNCH(gemm_nt256_kernel<2>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();

@@ -372,6 +372,15 @@ class Engine:
         ops.gemm_nt(A, l.wb, C, rows, l.out_f, l.in_f, epi, R=R, bias=bias, lda=A.shape[-1], ldb=l.in_f, ldc=C.shape[-1],
                     ldr=None if R is None else R.shape[-1])
 
+    def _mlp_gate_fwd(self, pre, xn, ab, h, rows):
+        """ab = fc1||fc3(xn), h = silu(a) * b - one launch where the shape allows it"""
+        l = self.lin[f"{pre}.mlp.fc13"]
+        if ops.swiglu_fwd_fusable(self.Fp, l.in_f) and rows >= 4096:
+            ops.gemm_nt_swiglu_fwd(xn, l.wb, ab, h, rows, self.Fp, l.in_f, ldx=xn.shape[-1], ldw=l.in_f)
+        else:
+            self._lin_fwd(f"{pre}.mlp.fc13", xn, ab, rows)
+            ops.swiglu_fwd(ab, h, rows, self.Fp)
+
     def _lin_bwd(self, name, dY, X, dX, rows):
         """dX(bf16) = dY @ W ; dW += dY^T @ X."""
         l = self.lin[name]
@@ -457,8 +466,7 @@ class Engine:
             self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], ce["ks"], ce["ke"], N, 1, B, N, N)
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
             ops.layernorm_fwd(w["xm"][:RN], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
-            self._lin_fwd(f"{pre}.mlp.fc13", w["ln2"], w["ab"], RN)
-            ops.swiglu_fwd(w["ab"], w["h"], RN, Fp)
+            self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RN)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RN, L.EPI_RESID, R=w["xm"])
         ops.layernorm_fwd(self.x_enc_out[:RN], self.p["encoder_norm.weight"], self.xe, self.st_en[0], self.st_en[1], eps=cfg.eps)
         # context = decoder_proj_context(x) + encoder_emb   (egom2p_model.py:722)
@@ -480,8 +488,7 @@ class Engine:
             self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N)
             self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["xo"], w["x2"], RM, L.EPI_RESID, R=w["x1"])
             ops.layernorm_fwd(w["x2"][:RM], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
-            self._lin_fwd(f"{pre}.mlp.fc13", w["ln2"], w["ab"], RM)
-            ops.swiglu_fwd(w["ab"], w["h"], RM, Fp)
+            self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RM)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RM, L.EPI_RESID, R=w["x2"])
         # decoder_norm, rows written modality-grouped (the row order of y[decoder_mod_mask == id], :633)
         ops.layernorm_fwd(self.y_out[:RM], self.p["decoder_norm.weight"], self.yn, self.st_dn[0], self.st_dn[1],
@@ -695,8 +702,7 @@ class Engine:
                 self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
                 self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
                 ops.layernorm_fwd(xn[:RN], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
-                self._lin_fwd(f"{pre}.mlp.fc13", w["ln"], w["ab"], RN)
-                ops.swiglu_fwd(w["ab"], w["h"], RN, Fp)
+                self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
                 self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
             ops.layernorm_fwd(x[:RN], self.p["encoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
             self._lin_fwd("decoder_proj_context.weight", w["ln"], w["ctx"], RN, L.EPI_BIAS_RESID, R=w["emb"],
@@ -725,8 +731,7 @@ class Engine:
                 # bias-free proj keeps it 0, so the cross-attention residual is the identity
                 y, yn = yn, y
             ops.layernorm_fwd(y[:RM], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
-            self._lin_fwd(f"{pre}.mlp.fc13", w["ln"], w["ab"], RM)
-            ops.swiglu_fwd(w["ab"], w["h"], RM, Fp)
+            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RM)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RM, L.EPI_RESID, R=y)
             y, yn = yn, y
         ops.layernorm_fwd(y[:RM], self.p["decoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)

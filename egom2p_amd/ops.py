@@ -102,6 +102,20 @@ def swiglu_fwd(ab, h, rows, F):
     check(L.load().ego_swiglu_fwd(_p(ab), _p(h), rows, F, _stream()), "ego_swiglu_fwd")
 
 
+def swiglu_fwd_fusable(F, K):
+    """shapes the fused fc1||fc3 + gate launch accepts (else: gemm_nt + swiglu_fwd)"""
+    return F % 128 == 0 and K % 64 == 0 and K >= 128 and os.environ.get("EGOM2P_FUSE_SWIGLU_FWD", "1") != "0"
+
+
+def gemm_nt_swiglu_fwd(X, W13, ab, h, M, F, K, ldx=None, ldw=None):
+    """ab[M,2F] = X[M,K] @ W13[2F,K]^T, h[M,F] = swiglu(ab) in one launch."""
+    _need_cuda(X)
+    ldx = X.stride(-2) if ldx is None else ldx
+    ldw = W13.stride(-2) if ldw is None else ldw
+    check(L.load().ego_gemm_nt_swiglu_fwd(_p(X), ldx, _p(W13), ldw, _p(ab), ab.stride(-2), _p(h), h.stride(-2), M, F, K, _stream()),
+          "ego_gemm_nt_swiglu_fwd")
+
+
 def swiglu_bwd_fusable(F, K):
     """shapes the fused fc2-dgrad + gate-backward launch accepts (else: gemm_nt + swiglu_bwd)"""
     return F % 256 == 0 and K % 64 == 0 and K >= 128 and os.environ.get("EGOM2P_FUSE_SWIGLU_BWD", "1") != "0"

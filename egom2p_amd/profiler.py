@@ -17,6 +17,11 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
 
 
+def detail_names() -> bool:
+    import os
+    return os.environ.get("EGOM2P_PROFILE_DETAIL") == "1"
+
+
 class KernelTimer:
     def __init__(self):
         self.records = []      # (class, flops, bytes, start_event, end_event)
@@ -51,6 +56,9 @@ class KernelTimer:
 
         def c_gemm_nt_swiglu_bwd(dY, W2t, ab, dab, M, F, K, **kw):
             return 2.0 * M * F * K, 2.0 * (M * K + F * K) + 8.0 * M * F       # ab read + dab write, 2 x 2 B x 2F each
+
+        def c_gemm_nt_swiglu_fwd(X, W13, ab, h, M, F, K, **kw):
+            return 4.0 * M * F * K, 2.0 * (M * K + 2 * F * K) + 6.0 * M * F       # ab write (2 x 2 B) + h write (2 B) per column
 
         def c_gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_range=None, **kw):
             m = min(M, rows_of(m_range, M))
@@ -99,16 +107,18 @@ class KernelTimer:
             return 0.0, n * V * 4.0
 
         table = {
-            "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
+            "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_nt_swiglu_fwd": c_gemm_nt_swiglu_fwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
             "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
             "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
         }
         other = ["compact", "embed_fwd", "embed_bwd", "loss_perm", "loss_finalize", "cast_weight", "cast_f32_bf16",
                  "bias_grad", "grad_sqnorm", "adamw_step"]
         saved = {}
+        # the fused launches are the same device kernel (gemm_nt256_kernel<EK>) behind other entry points: one class
+        family = {"gemm_nt_swiglu_fwd": "gemm_nt", "gemm_nt_swiglu_bwd": "gemm_nt"}
         for name, cost in table.items():
             saved[name] = getattr(ops, name)
-            setattr(ops, name, self._wrap(name, saved[name], cost))
+            setattr(ops, name, self._wrap(family.get(name, name) if not detail_names() else name, saved[name], cost))
         for name in other:
             saved[name] = getattr(ops, name)
             setattr(ops, name, self._wrap("other:" + name, saved[name], lambda *a, **k: (0.0, 0.0)))

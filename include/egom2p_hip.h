@@ -132,6 +132,12 @@ int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_
 /* SwiGLU gate on the fused fc1||fc3 output ab[rows, 2F] (GatedMlp, egom2p_utils.py:167-169). */
 int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream);
 int ego_swiglu_bwd(const void* ab, const void* dh, void* dab, long rows, int F, hipStream_t stream);
+/* fc1||fc3 and the gate in one launch: ab[M,2F] = X[M,K] @ W13[2F,K]^T and h = bf16(bf16(silu(a)) * b) (GatedMlp.forward,
+ * egom2p_utils.py:167-169).  A tile of the GEMM is 128 columns of the a half and the matching 128 columns of the b half,
+ * so the gate is formed in the epilogue; ab is still stored (the backward reads it) but never read back.  Bitwise the
+ * result of ego_gemm_nt_bf16(EPI_BF16) + ego_swiglu_fwd.  F % 128 == 0, K % 64 == 0, K >= 128 (else EGO_ERR_ARG). */
+int ego_gemm_nt_swiglu_fwd(const void* X, long ldx, const void* W13, long ldw, void* ab, long ld_ab, void* h, long ld_h,
+                           int M, int F, int K, hipStream_t stream);
 /* The fc2 input gradient and the gate backward in one launch: dh = dY[M,K] @ W2t[F,K]^T is formed tile by tile in
  * the GEMM and consumed by its epilogue (autograd of GatedMlp.forward, egom2p_utils.py:167-169, through fc2 and the
  * SiLU gate); dab[M,2F] receives exactly what ego_gemm_nt_bf16(EPI_BF16) + ego_swiglu_bwd would write, without the

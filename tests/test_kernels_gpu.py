@@ -102,6 +102,33 @@ def test_gemm_nt256_fp32_epilogues():
     assert _rel(out, R2 + _bf(ref + _bf(bias).float()).float()) < 2e-3
 
 
+def test_gemm_nt_swiglu_fwd_fused_equals_two_calls():
+    """fc1||fc3 + gate in one launch writes bit for bit what gemm_nt(EPI_BF16) + swiglu_fwd write (same kernel family)"""
+    try:
+        ops.gemm_kernel_mode(2, 1)                      # reference GEMM on the 256x256 kernel too: same summation order
+        for M, F, K in [(4200, 2048, 768), (8192 + 9, 384, 128)]:
+            X = _bf(torch.randn(M, K, device=DEV))
+            W13 = _bf(torch.randn(2 * F, K, device=DEV) * 0.05)
+            ab_ref = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+            h_ref = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(X, W13, ab_ref, M, 2 * F, K, L.EPI_BF16)
+            ops.swiglu_fwd(ab_ref, h_ref, M, F)
+            ab = torch.full((M + 1, 2 * F), 9.0, device=DEV, dtype=torch.bfloat16)
+            h = torch.full((M + 1, F), 9.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt_swiglu_fwd(X, W13, ab, h, M, F, K)
+            if (2 * F) % 256 == 0:
+                assert torch.equal(ab[:M], ab_ref)
+                assert torch.equal(h[:M], h_ref)
+            else:                                        # reference ran on the 128x128 kernel: rounding-level agreement
+                assert _rel(ab[:M].float(), ab_ref.float()) < 1e-3 and _rel(h[:M].float(), h_ref.float()) < 2e-3
+            assert (ab[M:] == 9).all() and (h[M:] == 9).all()
+            # against plain torch
+            ref = X.float() @ W13.float().t()
+            assert _rel(ab[:M].float(), ref) < 4e-3
+    finally:
+        ops.gemm_kernel_mode(1, 1)
+
+
 def test_gemm_nt_swiglu_bwd_fused_equals_two_calls():
     """fc2 dgrad + gate backward in one launch writes bit for bit what gemm_nt(EPI_BF16) + swiglu_bwd write"""
     for M, F, K in [(4200, 2048, 768), (8192 + 9, 512, 128)]:
