@@ -875,27 +875,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
         p_off[j] = (unsigned)(r * p.ldp * 2 + c * 16);
         q_off[j] = (unsigned)(r * p.ldq * 2 + c * 16);
     }
-    auto dma = [&](int s, int m0, int j) {
+    // Q (the saved forward activation, HBM-cold) sits in a 3-deep ring and is fetched two steps ahead, P (the gradient,
+    // written just before) in a 2-deep ring one step ahead: 3 x 32 + 2 x 32 KiB = the whole LDS.  Per wave and step the
+    // four P pieces are issued before the four Q pieces, so vmcnt(4) means P(g+1) and the older Q(g+1) have landed.
+    auto dmaP = [&](int slot, int m0, int j) {
         const int rows = min(BK, M - m0);
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Pb + (long)m0 * p.ldp), 0, (int)(unsigned)((long)(rows - 1) * p.ldp * 2 + 512), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
+                                                 16, p_off[j], 0, 0, 0);
+    };
+    auto dmaQ = [&](int slot, int m0, int j) {
+        const int rows = min(BK, M - m0);
         const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Qb + (long)m0 * p.ldq), 0, (int)(unsigned)((long)(rows - 1) * p.ldq * 2 + 512), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + (wave * 4 + j) * 1024),
-                                                 16, p_off[j], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)(smem + s * S2_BYTES + T2_BYTES + (wave * 4 + j) * 1024),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (wave * 4 + j) * 1024),
                                                  16, q_off[j], 0, 0, 0);
     };
-    // transposed-read addresses (stage 0): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16
-    // block; 16-column block ci of row r sits at 32-byte chunk ci ^ tn_f(r), and tn_f is the same for r0, r0+4, r0+32
+    // transposed-read addresses (slot 0 of each ring): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
+    // 4x16 block; 16-column block ci of row r sits at 32-byte chunk ci ^ tn_f(r), and tn_f is the same for r0, r0+4, r0+32
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
     const int r0 = 8 * g + tq, f = tn_f(r0);
     unsigned pa[8], qa[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pa[i] = lds0 + r0 * 512 + ((grp * 8 + (i ^ f)) << 5) + tp * 8;
+    for (int i = 0; i < 8; ++i) pa[i] = lds0 + 3 * RA_BYTES + r0 * 512 + ((grp * 8 + (i ^ f)) << 5) + tp * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qa[i] = lds0 + T2_BYTES + r0 * 512 + (((wc * 4 + i) ^ f) << 5) + tp * 8;
+    for (int i = 0; i < 4; ++i) qa[i] = lds0 + r0 * 512 + (((wc * 4 + i) ^ f) << 5) + tp * 8;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -905,9 +911,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     bf16x8 pf[4][2], qf[2][2];
 
     if (st0 < st1) {
+        // prologue: Q(0), P(0), then Q(1); the first two must have landed
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma(0, st0 * BK, j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = 0; j < 4; ++j) dmaQ(0, st0 * BK, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dmaP(0, st0 * BK, j);
+        if (st0 + 1 < st1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dmaQ(1, (st0 + 1) * BK, j);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         bar_pinned();
         if (grp == 1) bar_pinned();
 
@@ -932,32 +947,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     __builtin_amdgcn_s_setprio(0);
 
         // the Q fragments of column half 0 serve quadrants (0,0) and (1,0): they stay in registers (q0) from phase 0 to
-        // phase 3 instead of being read from LDS twice - the transposed reads are the scarce resource of this kernel
+        // phase 3 instead of being read from LDS twice
         bf16x8 q0[2][2];
+        int sq = 0, spn = 1, sqn = 2;          // Q slot of this step; P slot / Q slot the DMA of this step fills
         for (int st = st0; st < st1; ++st) {
-            const unsigned so = ((st - st0) & 1) * S2_BYTES;
-            const int sn = ((st - st0) & 1) ^ 1, mn = (st + 1) * BK;
-            const bool more = st + 1 < st1;
-            TLOAD_P(0, so) TLOAD_Q(q0, 0, so)
-            if (more && grp == 1) { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); }
+            const unsigned soP = (unsigned)(spn ^ 1) * RA_BYTES, soQ = (unsigned)sq * RA_BYTES;
+            const int m1 = (st + 1) * BK, m2 = (st + 2) * BK;
+            const bool fp = st + 1 < st1, fq = st + 2 < st1;
+            TLOAD_P(0, soP) TLOAD_Q(q0, 0, soQ)
+            if (grp == 1 && fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); }
             bar_pinned();
             TCOMPUTE(q0, 0, 0)
             bar_pinned();
-            TLOAD_Q(qf, 1, so)
-            if (more) { if (grp == 1) { dma(sn, mn, 3); } else { dma(sn, mn, 0); dma(sn, mn, 1); dma(sn, mn, 2); } }
+            TLOAD_Q(qf, 1, soQ)
+            if (grp == 1) { if (fp) dmaP(spn, m1, 3); if (fq) { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
+            else if (fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); }
             bar_pinned();
             TCOMPUTE(qf, 0, 1)
             bar_pinned();
-            TLOAD_P(1, so)
-            if (more && grp == 0) { dma(sn, mn, 3); }
+            TLOAD_P(1, soP)
+            if (grp == 1) { if (fq) { dmaQ(sqn, m2, 2); dmaQ(sqn, m2, 3); } }
+            else { if (fp) dmaP(spn, m1, 3); if (fq) { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
             bar_pinned();
             TCOMPUTE(qf, 1, 1)
             bar_pinned();
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (grp == 0 && fq) { dmaQ(sqn, m2, 2); dmaQ(sqn, m2, 3); }
+            if (grp == 1) { if (fq) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
             TCOMPUTE(q0, 1, 0)
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (grp == 0) { if (fq) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
+            sq = sq == 2 ? 0 : sq + 1;
+            sqn = sqn == 2 ? 0 : sqn + 1;
+            spn ^= 1;
         }
 #undef TLOAD_P
 #undef TLOAD_Q
@@ -1016,7 +1038,7 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
     if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
     if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
@@ -1108,7 +1130,7 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && M > 0 && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
     const int tiles256 = (Ni / 256) * (Nj / 256);
     if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
-        EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT2_LDS, stream, a);
+        EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT3_LDS, stream, a);
     } else {
         const int tiles = (Ni / BM) * (Nj / BN);
         EGO_LAUNCH(gemm_tn_kernel, dim3(tiles * splits), dim3(256), GEMM_LDS, stream, a);
