@@ -38,7 +38,8 @@ struct AttnArgs {
     float scale;
     // backward only
     const bf16_t* dO; long do_bs, do_rs;
-    const float* DELTA;         // [B,H,Nq]
+    const float* DELTA;         // [B,H,Nq]  (read by the dK/dV kernel)
+    float* DELTA_OUT;           // same buffer, written by the dQ kernel
     bf16_t* dQ; long dq_bs, dq_rs;
     bf16_t* dK; long dk_bs, dk_rs;
     bf16_t* dV; long dv_bs, dv_rs;
@@ -325,26 +326,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-// ---------------------------------------------------------------------------------------------
-__global__ void attn_delta_kernel(const bf16_t* O, long o_bs, long o_rs, const bf16_t* dO, long do_bs, long do_rs,
-                                  float* DELTA, int B, int H, int Nq) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= B * Nq) return;
-    const int b = wave / Nq, q = wave % Nq;
-    const bf16_t* o = O + (long)b * o_bs + (long)q * o_rs;
-    const bf16_t* g = dO + (long)b * do_bs + (long)q * do_rs;
-    for (int c = lane; c < H * 16; c += 64) {      // 4-element chunks; 16 chunks per head
-        const u32x2 a = *(const u32x2*)(o + c * 4), d = *(const u32x2*)(g + c * 4);
-        float s = bf16_to_f32(a[0] & 0xffff) * bf16_to_f32(d[0] & 0xffff) + bf16_to_f32(a[0] >> 16) * bf16_to_f32(d[0] >> 16) +
-                  bf16_to_f32(a[1] & 0xffff) * bf16_to_f32(d[1] & 0xffff) + bf16_to_f32(a[1] >> 16) * bf16_to_f32(d[1] >> 16);
-#pragma unroll
-        for (int o_ = 8; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 64);
-        if ((lane & 15) == 0) DELTA[((long)b * H + (c >> 4)) * Nq + q] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward, query-major: dQ
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -378,7 +359,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
         gf[s] = *(const bf16x8*)(Gp + 16 * s + 8 * hh);
     }
     const float lse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];
-    const float delta = p.DELTA[((long)b * p.H + h) * p.Nq + qrow];
+    // delta[b,h,q] = sum_d dO * O of this wave's rows: formed here from the dO fragments already in registers (each
+    // half-wave holds 32 of the 64 dims) and stored for the dK/dV kernel, which runs behind this one on the stream
+    float delta = 0.f;
+    {
+        const bf16_t* Op = p.O + (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 of = *(const bf16x8*)(Op + 16 * s + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += (float)of[e] * (float)gf[s][e];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        if (hh == 0 && q0 + ql < p.Nq) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = delta;
+    }
     const float dgs = delta * gsc;
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
@@ -680,20 +674,14 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
     a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
-    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs;
+    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA; a.DELTA_OUT = DELTA;
     a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
     if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
-    {
-        const long waves = (long)B * Nq;
-        const int blocks = (int)((waves * 64 + 255) / 256);
-        EGO_LAUNCH(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)O, o_bs, o_rs,
-                           (const bf16_t*)dO, do_bs, do_rs, DELTA, B, H, Nq);
-        LAUNCH_CHECK();
-    }
     EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128)), dim3(256), 0, stream, a);
