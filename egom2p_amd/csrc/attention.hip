@@ -443,8 +443,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 // ---------------------------------------------------------------------------------------------
 // backward, key-major: dK, dV
 // ---------------------------------------------------------------------------------------------
-constexpr int AUX_OFF = 4 * TILE_BYTES;           // per stage: lse2[64] delta[64] ks[64] ke[64] = 1 KiB
-constexpr int AGG_OFF = AUX_OFF + 2 * 1024;         // per q tile {min ks, max ks, min ke, max ke}
+constexpr int DKV_STAGES = 3;                     // Q / dO ring, filled two q tiles ahead
+constexpr int AUX_OFF = DKV_STAGES * 2 * TILE_BYTES;   // per stage: lse2[64] delta[64] ks[64] ke[64] = 1 KiB
+constexpr int AGG_OFF = AUX_OFF + DKV_STAGES * 1024;   // per q tile {min ks, max ks, min ke, max ke}
 constexpr int DKV_MAX_QTILES = 512;
 constexpr int DKV_LDS = AGG_OFF + DKV_MAX_QTILES * 16;
 
@@ -475,25 +476,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int* KSb = p.ks + b * p.r_bs;
     const int* KEb = p.ke + b * p.r_bs;
 
-    // Q / dO tiles arrive by LDS-DMA (dma_tile64); the four per-row scalars are staged through registers of wave 0
-    float a_lse = 0.f, a_del = 0.f;
-    int a_ks = INT_MAX, a_ke = 0;
+    // Q / dO tiles arrive by LDS-DMA (dma_tile64); the four per-row scalars are staged through registers of wave 0:
+    // load_tile only issues the raw loads (first, so that the wait for them leaves the younger DMA in flight), store_aux
+    // derives the stored values at the end of the iteration - nothing in between depends on the loads
+    float r_lse = 0.f, r_del = 0.f;
+    int r_ks = 0, r_ke = 0, r_row = 0;
     const DmaOff qoff = dma_off(p.q_rs, wave, lane), goff = dma_off(p.do_rs, wave, lane);
     const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(Qb, p.q_rs, p.Nq), grs = slice_rsrc(Gb, p.do_rs, p.Nq);
     auto load_tile = [&](int qt, int s) {
+        if (tid < 64) {
+            r_row = qt * 64 + tid;
+            const int row = min(r_row, p.Nq - 1);
+            r_lse = LSEb[row]; r_del = DELb[row];
+            r_ks = KSb[row * p.r_rs]; r_ke = KEb[row * p.r_rs];
+        }
         dma_tile64(qrs, p.q_rs, qoff, qt * 64, smem + s * 2 * TILE_BYTES, wave);
         dma_tile64(grs, p.do_rs, goff, qt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
-        if (tid < 64) {
-            const int row = qt * 64 + tid;
-            if (row < p.Nq) {
-                a_lse = LSEb[row]; a_del = DELb[row] * p.scale;      // delta * scale: dS = P * fma(dP, scale, -delta*scale)
-                a_ks = KSb[row * p.r_rs]; a_ke = min(KEb[row * p.r_rs], p.Nk);
-                if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
-            } else { a_lse = 0.f; a_del = 0.f; a_ks = INT_MAX; a_ke = 0; }   // (the DMA zero-fills rows past Nq)
-        }
     };
     auto store_aux = [&](int s) {
         if (tid < 64) {
+            float a_lse = 0.f, a_del = 0.f;
+            int a_ks = INT_MAX, a_ke = 0;                     // rows past Nq (the DMA zero-fills them): never attended
+            if (r_row < p.Nq) {
+                a_lse = r_lse; a_del = r_del * p.scale;       // delta * scale: dS = P * fma(dP, scale, -delta*scale)
+                a_ks = r_ks; a_ke = min(r_ke, p.Nk);
+                if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
+            }
             float* af = (float*)(smem + AUX_OFF + s * 1024);
             int* ai = (int*)(smem + AUX_OFF + s * 1024 + 512);
             af[tid] = a_lse; af[64 + tid] = a_del; ai[tid] = a_ks; ai[64 + tid] = a_ke;
@@ -539,15 +547,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
     const int qt0 = (q_last < 0) ? 0 : q_first;
     const int nqt = (q_last < 0) ? 0 : q_last + 1;
+    // ring of DKV_STAGES q tiles, filled two tiles ahead; every tile is 4 DMA instructions of this wave, so "at most 4
+    // outstanding" means the older tile has landed
     if (qt0 < nqt) {
         load_tile(qt0, 0);
         store_aux(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (qt0 + 1 < nqt) {
+        load_tile(qt0 + 1, 1);
+        store_aux(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+    // The K / V fragments were fetched by plain global loads at kernel entry.  Their first use is inside the loop, and
+    // hipcc puts the s_waitcnt there: a vmcnt(0) executed in EVERY iteration, which also drains the LDS-DMA just issued
+    // for the tiles ahead (the whole prefetch serialised behind it).  Naming the registers here moves that wait in
+    // front of the loop.
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));
+    int s_ = 0;
     for (int qt = qt0; qt < nqt; ++qt) {
-        const int s_ = (qt - qt0) & 1;
-        if (qt + 1 < nqt) load_tile(qt + 1, s_ ^ 1);       // that stage was last read before the previous barrier
+        const bool ahead = qt + 2 < nqt;
+        const int s2 = s_ >= 1 ? s_ - 1 : 2;               // stage of tile qt + 2: last read before the previous barrier
+        if (ahead) load_tile(qt + 2, s2);
         const char* Qt = smem + s_ * 2 * TILE_BYTES;
         const char* Gt = Qt + TILE_BYTES;
         const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);
@@ -629,9 +653,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                 }
             }
         }
-        if (qt + 1 < nqt) store_aux(s_ ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (ahead) {
+            store_aux(s2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
+        s_ = (s_ == 2) ? 0 : s_ + 1;
     }
     if (kidx < p.Nk) {
         store_rows_bf16(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * 64, dkt, 1.f, hh);
