@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 // backward, query-major: dQ
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
     pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
     const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
     const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
-    int* rng = (int*)(smem + 4 * TILE_BYTES);
+    int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
     if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
     __syncthreads();
     const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
@@ -388,12 +388,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
 
+    const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
+    // K / V ring of FWD_STAGES tiles, filled two tiles ahead (see attn_fwd_kernel); the Q / dO fragments and row scalars
+    // fetched at kernel entry are waited for here, not at their first use inside the loop
     if (kt0 < kt1) dma_tile(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (kt0 + 1 < kt1) {
+        dma_tile(kt0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(qf[s]), "v"(gf[s]));
+    int s_ = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int s_ = (kt - kt0) & 1;
-        if (kt + 1 < kt1) dma_tile(kt + 1, s_ ^ 1);      // that stage was last read before the previous barrier
+        const bool ahead = kt + 2 < kt1;
+        if (ahead) dma_tile(kt + 2, s_ >= 1 ? s_ - 1 : 2);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
         // dS^T = P o (dP^T - delta) * scale.  Interior tiles (every row of the wave sees all 64 keys) skip the
@@ -410,6 +421,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp, 0, 0, 0);
             }
+            // K^T fragments of this 32-key half (dQ operands): asm transposed reads, in flight under the arithmetic
+            s16x4 kfr[4][2];
+            if (kb == 0) tr_issue<0, 0>(tra, s_ * 2 * TILE_BYTES, kfr); else tr_issue<0, 2>(tra, s_ * 2 * TILE_BYTES, kfr);
             if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -425,16 +439,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
                     st[r] = pv * __builtin_fmaf(dp[r], gsc, -dgs);
                 }
             }
+            lgkm_wait_tied<0>(kfr);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const bf16x8 dsf = pack8(st, x);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, db, 2 * kb + x, lane), dsf, dqt[db], 0, 0, 0);
+                    dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(kfr[2 * x + db][0], kfr[2 * x + db][1]), dsf, dqt[db], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        s_ = (s_ == 2) ? 0 : s_ + 1;
     }
     if (q0 + ql < p.Nq)
         store_rows_bf16(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * 64, dqt, 1.f, hh);
