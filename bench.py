@@ -132,7 +132,9 @@ def main():
     e2e_tflops = f_step_per_gpu / (dt / args.steps) / 1e12
 
     out = {
-        "metric": "multimodal tokens/sec (ego-b 400M, 10300-tok clips), training fwd+bwd+allreduce+AdamW",
+        "metric": ("multimodal tokens/sec (ego-b 400M, 10300-tok clips), training fwd+bwd+allreduce+AdamW"
+                   if args.model == "egom2p_base_12e_12d_swiglu_nobias" else
+                   f"multimodal tokens/sec ({args.model}, 10300-tok clips), training fwd+bwd+allreduce+AdamW"),
         "value": value, "unit": "clip-positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",

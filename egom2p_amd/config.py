@@ -81,5 +81,6 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     "ego_tiny_2e_2d": ModelCfg("ego_tiny_2e_2d", 128, 2, 2, 2, modalities=("tok_cam", "tok_gaze")),
     "ego_b_2e_2d": ModelCfg("ego_b_2e_2d", 768, 2, 2, 12),
     "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
+    "ego_L_1152_2e_2d": ModelCfg("ego_L_1152_2e_2d", 1152, 2, 2, 18),       # ego-L width (BASELINE config 5) at parity-test depth
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),
 }

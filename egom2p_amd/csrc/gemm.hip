@@ -1073,7 +1073,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
     // partly filled single round on (dgrad of the logits: 1030-1110 vs 800-950 TF/s); few tiles with K = 768 and the
     // residual epilogue stay on the 128x128 kernel (two workgroups per CU hide each other's epilogue).
-    const bool legal256 = N % 256 == 0 && K >= 2 * BK && 256L * lda * 2 < 0x7ff00000L && (long)N * ldb * 2 < 0xfff00000L;
+    const bool legal256 = N % 128 == 0 && K >= 2 * BK && 256L * lda * 2 < 0x7ff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
     if (big) {
         if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }

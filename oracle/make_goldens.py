@@ -255,6 +255,9 @@ CASES = {
     # ego-b width, 2+2 layers, ragged budgets with padding
     "b2_ragged": dict(cfg_name="ego_b_2e_2d", batch=3, n_enc=2048, n_dec=2048, budgets="dirichlet", seed=4,
                       full_float=False, py_seed=14),
+    # ego-L width (D = 1152, 18 heads of 64, F = 3072: BASELINE config 5), 2+2 layers, canonical split, B=1
+    "L2": dict(cfg_name="ego_L_1152_2e_2d", batch=1, n_enc=2048, n_dec=2048, budgets=None, seed=6,
+               full_float=False, py_seed=16),
     # full-depth ego-b (400M), canonical split, B=1
     "b12": dict(cfg_name="egom2p_base_12e_12d_swiglu_nobias", batch=1, n_enc=2048, n_dec=2048, budgets=None,
                 seed=5, full_float=False, py_seed=15),

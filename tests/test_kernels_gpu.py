@@ -65,7 +65,8 @@ def test_gemm_nt_row_range():
     assert (C[:130] == 7).all() and (C[463:] == 7).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(8292, 5120, 192), (8192, 5120, 64), (16384 + 7, 2560, 128), (65536, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(8292, 5120, 192), (8192, 5120, 64), (16384 + 7, 2560, 128), (65536, 768, 768),
+                                   (40000, 1152, 1152)])      # ego-L width: the last column tile is half empty
 def test_gemm_nt256_persistent(M, N, K):
     """>= 640 tiles of 256 x 256 with a bf16 output run on the persistent staggered kernel: several tiles per
     workgroup, odd / single K-step counts (stage parity carries over the tile seam), ragged last row tile."""

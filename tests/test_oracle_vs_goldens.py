@@ -20,7 +20,7 @@ FP32_TOL = 2e-5
 
 CASES = ["tiny", "tiny_pad", "b2", "b2_ragged"]
 if os.environ.get("EGOM2P_SLOW") == "1":
-    CASES.append("b12")
+    CASES += ["b12", "L2"]
 
 
 def _setup(case):
