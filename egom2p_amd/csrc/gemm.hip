@@ -817,6 +817,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int gj = j0 + wj * 64 + j * 16 + (lane >> 4) * 4;
             const f32x4 v = acc[i][j];
+            if (gi >= p.Ni || gj >= p.Nj) continue;          // half-empty last tile (its operand columns held other rows' data)
             if (p.splits > 1) {
                 *(f32x4*)(p.slab + ((long)split * p.Ni + gi) * p.Nj + gj) = v;
             } else {
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     int M = p.M;
     long moff = 0;
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
-    const int tiles_j = p.Nj / 256, ntile = (p.Ni / 256) * tiles_j;
+    const int tiles_j = (p.Nj + 255) / 256, ntile = ((p.Ni + 255) / 256) * tiles_j;      // a last tile may be half empty
     const int split = blockIdx.x / ntile;
     const int t = xcd_remap(blockIdx.x % ntile, ntile);
     const int i0 = (t / tiles_j) * 256, j0 = (t % tiles_j) * 256;
@@ -881,14 +882,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     auto dmaP = [&](int slot, int m0, int j) {
         const int rows = min(BK, M - m0);
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(Pb + (long)m0 * p.ldp), 0, (int)(unsigned)((long)(rows - 1) * p.ldp * 2 + 512), 0x00020000);
+            (void*)(Pb + (long)m0 * p.ldp), 0, (int)(unsigned)((long)(rows - 1) * p.ldp * 2 + 2 * min(256, p.Ni - i0)), 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
                                                  16, p_off[j], 0, 0, 0);
     };
     auto dmaQ = [&](int slot, int m0, int j) {
         const int rows = min(BK, M - m0);
         const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(Qb + (long)m0 * p.ldq), 0, (int)(unsigned)((long)(rows - 1) * p.ldq * 2 + 512), 0x00020000);
+            (void*)(Qb + (long)m0 * p.ldq), 0, (int)(unsigned)((long)(rows - 1) * p.ldq * 2 + 2 * min(256, p.Nj - j0)), 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (wave * 4 + j) * 1024),
                                                  16, q_off[j], 0, 0, 0);
     };
@@ -995,6 +996,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int gj = j0 + wc * 64 + j * 16 + (lane >> 4) * 4;
             const f32x4 v = acc[i][j];
+            if (gi >= p.Ni || gj >= p.Nj) continue;          // half-empty last tile (its operand columns held other rows' data)
             if (p.splits > 1) {
                 *(f32x4*)(p.slab + ((long)split * p.Ni + gi) * p.Nj + gj) = v;
             } else {
@@ -1127,8 +1129,8 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
     // 256x256 staggered kernel, one workgroup per CU
-    const bool legal256 = (Ni % 256 == 0) && (Nj % 256 == 0) && M > 0 && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
-    const int tiles256 = (Ni / 256) * (Nj / 256);
+    const bool legal256 = (Ni % 128 == 0) && (Nj % 128 == 0) && M > 0 && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
+    const int tiles256 = ((Ni + 255) / 256) * ((Nj + 255) / 256);
     if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
         EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT3_LDS, stream, a);
     } else {

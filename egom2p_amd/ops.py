@@ -81,8 +81,8 @@ def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, wgs128=512, wgs256=256):
         return 1
     steps = max(1, (rows + 63) // 64)
     cap = max(1, slab_numel // (Ni * Nj))
-    if Ni % 256 == 0 and Nj % 256 == 0 and Ni * Nj >= int(os.environ.get("EGO_GEMM_TN256_AREA", 512 * 1024)) and L.tn256_enabled():
-        return max(1, min(steps, wgs256 // ((Ni // 256) * (Nj // 256)), cap))
+    if Ni % 128 == 0 and Nj % 128 == 0 and Ni * Nj >= int(os.environ.get("EGO_GEMM_TN256_AREA", 512 * 1024)) and L.tn256_enabled():
+        return max(1, min(steps, wgs256 // (((Ni + 255) // 256) * ((Nj + 255) // 256)), cap))
     return max(1, min(steps, wgs128 // ((Ni // 128) * (Nj // 128)), cap))
 
 

@@ -161,7 +161,9 @@ def test_gemm_nt256_row_range():
 # ------------------------------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("M,Ni,Nj,splits", [(1000, 256, 128, 1), (4096, 768, 768, 4), (777, 2304, 768, 3), (64, 128, 128, 1),
                                              # whole-step shapes with >= 128 (tile, split) pairs run on the 256x256 staggered kernel
-                                             (8192, 2304, 768, 9), (2368, 2304, 768, 9), (16384, 1024, 1024, 8), (64 * 5, 2048, 1024, 5)])
+                                             (8192, 2304, 768, 9), (2368, 2304, 768, 9), (16384, 1024, 1024, 8), (64 * 5, 2048, 1024, 5),
+                                             # ego-L width: 13.5 x 4.5 tiles, the last row / column tiles are half empty
+                                             (4096 + 33, 3456, 1152, 4)])
 def test_gemm_tn(M, Ni, Nj, splits):
     P = _bf(torch.randn(M, Ni, device=DEV))
     Q = _bf(torch.randn(M, Nj, device=DEV))
