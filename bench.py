@@ -96,8 +96,8 @@ def main():
     eng.init_random(seed=0)                      # same weights on every rank (DDP broadcast semantics)
     budgets = synth.CANONICAL_BUDGETS
     pool = 2                                     # distinct micro-batches per rank, cycled (inputs stay in HBM)
-    mbs_cpu = [synth.make_clip_batch(cfg, mb, budgets, seed=100 + rank, sample_offset=i * mb) for i in range(pool)]
-    mbs = [{k: {kk: vv.to(dev) for kk, vv in v.items()} for k, v in m.items()} for m in mbs_cpu]
+    # clips are synthesised on the device (ego_clip_synth: bit-identical to the host generator, no H2D copy)
+    mbs = [synth.make_clip_batch_device(cfg, mb, budgets, seed=100 + rank, sample_offset=i * mb, device=dev) for i in range(pool)]
     step = TrainStep(eng, lr=args.lr, weight_decay=0.05, clip_grad=1.0, world_size=world, seed=rank,
                      force_reducer=os.environ.get("EGOM2P_FORCE_REDUCER") == "1")
 
@@ -171,7 +171,8 @@ def main():
         out["kernel_breakdown"] = {k: {"ms": round(v["ms"], 3), "calls": v["calls"], "tflops": round(v["tflops"], 1),
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, eng, mbs_cpu[0], [m.name for m in cfg.mods], n_enc, n_dec)
+        clip_cpu = synth.make_clip_batch(cfg, 1, budgets, seed=100 + rank, sample_offset=0)      # same first clip, host copy
+        out["cpu_baseline"] = cpu_baseline(cfg, eng, clip_cpu, [m.name for m in cfg.mods], n_enc, n_dec)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

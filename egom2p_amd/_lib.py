@@ -55,6 +55,7 @@ _SIGS = {
                          i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
                          vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
+    "ego_clip_synth": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_swiglu_fwd": [vp, vp, i64, i32, vp],
     "ego_swiglu_bwd": [vp, vp, vp, i64, i32, vp],
     "ego_gemm_nt_swiglu_bwd": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp],

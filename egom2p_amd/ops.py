@@ -68,6 +68,13 @@ def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_ra
                                     M, splits, _p(slab), _stream()), "ego_gemm_tn_bf16")
 
 
+def clip_synth(key_ids, key_perm, k_in, k_tgt, n, vocab, ids, input_mask, target_mask, dam):
+    """one modality of the synthetic input contract for B = len(key_ids) clips, generated on the device"""
+    _need_cuda(ids)
+    check(L.load().ego_clip_synth(_p(key_ids), _p(key_perm), _p(k_in), _p(k_tgt), key_ids.numel(), n, vocab, _p(ids),
+                                  _p(input_mask), _p(target_mask), _p(dam), _stream()), "ego_clip_synth")
+
+
 def gemm_kernel_mode(nt256=1, tn256=1):
     """1 = tile family by shape (default), 0 = 128x128 kernels only, 2 = 256x256 wherever legal"""
     check(L.load().ego_gemm_kernel_mode(nt256, tn256), "ego_gemm_kernel_mode")

@@ -195,6 +195,33 @@ def make_clip_batch(cfg: ModelCfg, batch: int, budgets: Optional[Dict[str, Seque
     return out
 
 
+def make_clip_batch_device(cfg: ModelCfg, batch: int, budgets: Optional[Dict[str, Sequence[Tuple[int, int]]]] = None,
+                           seed: int = 0, sample_offset: int = 0, device: str = "cuda") -> Dict[str, Dict[str, torch.Tensor]]:
+    """`make_clip_batch` generated on the GPU (ego_clip_synth): same bits, no host tensors, no H2D copy.  Only the per-clip
+    stream keys (two sha256 per clip and modality) and the budgets are prepared on the host."""
+    from . import ops
+    out: Dict[str, Dict[str, torch.Tensor]] = {}
+    for m in cfg.mods:
+        n = m.max_tokens
+        bud = (budgets or CANONICAL_BUDGETS)[m.name]
+        if isinstance(bud[0], int):
+            bud = [tuple(bud)] * batch
+        assert all(k_in + k_tg <= n for k_in, k_tg in bud)
+        keys = np.array([[_key(f"clip{sample_offset + b}.{m.name}.ids", seed), _key(f"clip{sample_offset + b}.{m.name}.perm", seed)]
+                         for b in range(batch)], dtype=np.uint64)
+        kd = torch.from_numpy(keys.view(np.int64)).to(device)
+        kb = torch.tensor(bud, dtype=torch.int32, device=device)
+        ids = torch.empty((batch, n), dtype=torch.int64, device=device)
+        in_mask = torch.empty((batch, n), dtype=torch.bool, device=device)
+        tg_mask = torch.empty((batch, n), dtype=torch.bool, device=device)
+        dam = torch.empty((batch, n), dtype=torch.int32, device=device)
+        ops.clip_synth(kd[:, 0].contiguous(), kd[:, 1].contiguous(), kb[:, 0].contiguous(), kb[:, 1].contiguous(), n, m.vocab_size,
+                       ids, in_mask, tg_mask, dam)
+        shape = (batch,) + (m.grid if m.kind == "video" else (n,))
+        out[m.name] = {"tensor": ids.reshape(shape), "input_mask": in_mask, "target_mask": tg_mask, "decoder_attention_mask": dam}
+    return out
+
+
 def dirichlet_budgets(cfg: ModelCfg, batch: int, n_in: int, n_tgt: int, seed: int = 0,
                       alphas: Sequence[float] = (0.01, 0.1, 1.0, 10.0)) -> Dict[str, List[Tuple[int, int]]]:
     """Ragged budgets in the spirit of the reference's Dirichlet mixture

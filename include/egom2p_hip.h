@@ -146,6 +146,15 @@ int ego_gemm_nt_swiglu_fwd(const void* X, long ldx, const void* W13, long ldw, v
 int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, const void* ab, void* dab, long ld_ab,
                            int M, int F, int K, hipStream_t stream);
 
+/* ---- input contract on the device ------------------------------------------------------------ */
+/* Synthetic `mod_dict` entries of one modality for B clips (egom2p/data/masking.py:236-266 builds them on CPU workers:
+ * random permutation of the positions, first k_in inputs, next k_tgt targets, decoder_attention_mask = k_tgt at the
+ * first target).  ids[B,n] int64 in [0,vocab), masks[B,n] uint8 (1 = ignore), dam[B,n] int32.  key_ids / key_perm:
+ * one 64-bit stream key per clip (host: sha256 of "<seed>:clip<s>.<mod>.ids|perm"); bit-identical to
+ * egom2p_amd/synth.py:make_clip_batch.  n <= 8192. */
+int ego_clip_synth(const void* key_ids, const void* key_perm, const int* k_in, const int* k_tgt, int B, int n, int vocab,
+                   long* ids, void* input_mask, void* target_mask, int* dam, hipStream_t stream);
+
 /* ---- loss head ------------------------------------------------------------------------------- */
 
 /* F.cross_entropy(reduction='mean') per modality over bf16 logits rows [range[0], range[0]+range[1])

@@ -136,3 +136,17 @@ def test_embed_and_backward_and_perm():
         assert np.array_equal(tperm.cpu().numpy()[off:off + rows.size], tg[rows])
         off += rows.size
     assert (p[mm == -1] == -1).all()
+
+
+def test_clip_synth_on_device_is_bit_identical_to_host():
+    """the device generator of the input contract (masking.py:236-266 equivalent) reproduces synth.make_clip_batch"""
+    from egom2p_amd import synth
+    from egom2p_amd.config import MODEL_CFGS
+    cfg = MODEL_CFGS["egom2p_base_12e_12d_swiglu_nobias"]
+    for budgets, seed, off in ((None, 3, 0), (synth.dirichlet_budgets(cfg, 3, 2048, 2048, 9), 9, 5)):
+        B = 3
+        host = synth.make_clip_batch(cfg, B, budgets, seed=seed, sample_offset=off)
+        dev = synth.make_clip_batch_device(cfg, B, budgets, seed=seed, sample_offset=off)
+        for m in cfg.mods:
+            for k in ("tensor", "input_mask", "target_mask", "decoder_attention_mask"):
+                assert torch.equal(dev[m.name][k].cpu(), host[m.name][k]), (m.name, k)
