@@ -216,6 +216,37 @@ def test_gemm_tn256_range_ragged_and_split_rows():
     assert _rel(G, ref2) < 1e-5
 
 
+def test_ring_kernels_are_race_free_and_deterministic():
+    """The persistent NT and the TN 256-kernels order their LDS rings only by counted vmcnt + barriers (no fences): an
+    early read would still pass a tolerance check whenever the DMA happens to land first.  Screen for it: the kernels
+    are deterministic, so repeated launches (with other traffic in between) must reproduce the first result bit for bit."""
+    noise = torch.empty(64 * 1024 * 1024, device=DEV)
+    for M, N, K in [(16384 + 5, 2560, 128), (32768, 768, 768), (12288, 1152, 1152)]:
+        A = _bf(torch.randn(M, K, device=DEV)); B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+        C0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_kernel_mode(2, 1)
+        try:
+            ops.gemm_nt(A, B, C0, M, N, K, L.EPI_BF16)
+            for it in range(12):
+                noise.normal_()                                   # evict caches, shift timing
+                C = torch.zeros_like(C0)
+                ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16)
+                assert torch.equal(C, C0), (M, N, K, it)
+        finally:
+            ops.gemm_kernel_mode(1, 1)
+    slab = torch.empty(64 * 1024 * 1024 // 4, device=DEV)
+    for M, Ni, Nj in [(8192 + 17, 2304, 768), (16384, 768, 768), (4096, 3456, 1152)]:
+        P = _bf(torch.randn(M, Ni, device=DEV)); Q = _bf(torch.randn(M, Nj, device=DEV))
+        splits = ops.tn_splits(Ni, Nj, M, slab.numel())
+        G0 = torch.zeros(Ni, Nj, device=DEV)
+        ops.gemm_tn(P, Q, G0, Ni, Nj, M, splits=splits, slab=slab if splits > 1 else None)
+        for it in range(12):
+            noise.normal_()
+            G = torch.zeros(Ni, Nj, device=DEV)
+            ops.gemm_tn(P, Q, G, Ni, Nj, M, splits=splits, slab=slab if splits > 1 else None)
+            assert torch.equal(G, G0), (M, Ni, Nj, it)
+
+
 def test_gemms_on_operands_beyond_4gib():
     """the logit-gradient operand of a large micro-batch exceeds 4 GiB: the 256-kernels re-base their buffer
     descriptors per tile / per step, so 32-bit buffer offsets never limit the operand size"""
@@ -432,3 +463,34 @@ def test_adamw_matches_torch():
         ops.adamw_step(p, graw, m, v, 1e-3, 0.05, step, gscale=1.0, max_norm=1.0, sqnorm=sq, zero_grad=True)
         assert (graw == 0).all()
         assert _rel(p, pr.detach()) < 1e-6
+
+
+def test_attention_kernels_are_deterministic_under_load():
+    """same screen for the attention kernels' 3-stage LDS-DMA rings (forward, dQ, dK/dV)"""
+    B, H, N = 4, 12, 2048
+    D = H * 64
+    qkv = _bf(torch.randn(B, N, 3, D, device=DEV))
+    do = _bf(torch.randn(B, N, D, device=DEV))
+    ks = torch.zeros(B, N, dtype=torch.int32, device=DEV)
+    ke = torch.full((B, N), N, dtype=torch.int32, device=DEV)
+    ks[:, 1009:] = 1009; ke[:, :1009] = 1009                      # two blocks: partial tiles at the seam
+    noise = torch.empty(64 * 1024 * 1024, device=DEV)
+    p = qkv.data_ptr()
+
+    def run():
+        o = torch.zeros(B, N, D, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(B, H, N, device=DEV); delta = torch.zeros(B, H, N, device=DEV)
+        dqkv = torch.zeros_like(qkv)
+        ops.attn_fwd(p, N * 3 * D, 3 * D, p + 2 * D, N * 3 * D, 3 * D, p + 4 * D, N * 3 * D, 3 * D, o.data_ptr(), N * D, D,
+                     lse, ks, ke, N, 1, B, H, N, N, 0.125)
+        g = dqkv.data_ptr()
+        ops.attn_bwd(p, N * 3 * D, 3 * D, p + 2 * D, N * 3 * D, 3 * D, p + 4 * D, N * 3 * D, 3 * D, o.data_ptr(), N * D, D,
+                     do.data_ptr(), N * D, D, lse, delta, g, N * 3 * D, 3 * D, g + 2 * D, N * 3 * D, 3 * D, g + 4 * D,
+                     N * 3 * D, 3 * D, ks, ke, N, 1, B, H, N, N, 0.125)
+        return o, lse, dqkv
+
+    o0, l0, d0 = run()
+    for it in range(8):
+        noise.normal_()
+        o, l, d = run()
+        assert torch.equal(o, o0) and torch.equal(l, l0) and torch.equal(d, d0), it
