@@ -507,10 +507,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         } else if constexpr (EK == 2) {
             // The tile is dh = dY W2 (never stored): da = dh b s (1 + a (1 - s)), db = dh a s with s = sigmoid(a), written
             // to dab[:, n] and dab[:, N + n] (ego_swiglu_bwd's arithmetic on the bf16-rounded dh, bit for bit).  Two passes
-            // of 128 rows like the bf16 epilogue; a and b rows are fetched two groups ahead of their use.
+            // of 128 rows like the bf16 epilogue.
             const bf16_t* Xb = p.X + moff * p.ldx;
             bf16_t* Yb = (bf16_t*)p.C + moff * p.ldc;
-            // groups of 2 row slices (8 groups per tile, 4 per pass), two groups in flight
+            // groups of 2 row slices (8 groups per tile, 4 per pass)
             auto load_ab = [&](int g, u32x4 (&av)[2], u32x4 (&bv)[2]) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -550,9 +550,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                     }
                 }
             };
-            u32x4 a0[2], b0[2], a1[2], b1[2];
-            load_ab(0, a0, b0);
-            load_ab(1, a1, b1);
+            // The accumulators are rounded to bf16 first (64 registers instead of 128): that frees the room to have the a / b
+            // rows of half the tile in flight at any time (4 groups x 4 loads of 16 bytes per lane = 128 KiB per CU) - the
+            // epilogue is HBM-latency-bound at one workgroup per CU, so its time is the number of dependent round trips
+            u32x2 pk[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[i][j];
+                    pk[i][j] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+            u32x4 av[4][2], bv[4][2];                  // groups g and g + 4 share a register set
+#pragma unroll
+            for (int g = 0; g < 4; ++g) load_ab(g, av[g], bv[g]);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (grp == half) {
@@ -563,20 +574,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int slot = wc * 16 + j * 4 + (lane >> 4);
-                            const f32x4 v = acc[i][j];
-                            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                            *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
+                            *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = pk[i][j];
                         }
                     }
                 }
                 lds_barrier();
 #pragma unroll
-                for (int gg = 0; gg < 4; gg += 2) {
+                for (int gg = 0; gg < 4; ++gg) {
                     const int g = half * 4 + gg;
-                    process(g, a0, b0);
-                    load_ab(g + 2, a0, b0);
-                    process(g + 1, a1, b1);
-                    load_ab(g + 3, a1, b1);
+                    process(g, av[gg], bv[gg]);
+                    if (half == 0) load_ab(g + 4, av[gg], bv[gg]);
                 }
                 lds_barrier();
             }
