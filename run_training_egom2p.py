@@ -141,9 +141,9 @@ def train_one_epoch(model, loader, optimizer, scaler, args, epoch, start_steps, 
                 print(f"Loss is {lv}, stopping training", file=sys.stderr)
                 sys.exit(1)
             dt = time.time() - t0
-            gn = grad_norm.item() if grad_norm is not None else float("nan")
+            gn_txt = f"{grad_norm.item():.3f}" if grad_norm is not None else "-"        # accumulation micro-steps have no norm yet
             print(f"Epoch: [{epoch}] step {step} loss {lv:.4f} " + " ".join(f"{m}_loss {v.item():.3f}" for m, v in mod_loss.items()) +
-                  f" grad_norm {gn:.3f} lr {optimizer.param_groups[0]['lr']:.3e} clips/s/gpu {seen / max(dt, 1e-9):.1f}", flush=True)
+                  f" grad_norm {gn_txt} lr {optimizer.param_groups[0]['lr']:.3e} clips/s/gpu {seen / max(dt, 1e-9):.1f}", flush=True)
         if args.max_steps > 0 and step + 1 >= args.max_steps:
             break
     torch.cuda.synchronize()
