@@ -38,21 +38,46 @@ def flops_per_clip(cfg, budgets, n_enc, n_dec):
     return float(enc + dec + ctx + logits)
 
 
-def cpu_baseline(cfg, eng, md_cpu, order, n_enc, n_dec):
-    """Oracle (CPU restatement, fp32, all host cores): fwd+bwd of ONE clip of the same workload."""
+def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
+    """The oracle (CPU restatement of the reference's forward, validated against the reference's own outputs) timed on
+    the host cores: forward + backward of whole clips of the same workload.  SURVEY.md section 8(d) protocol = one
+    warm-up, then the median of 5 runs, for B in {1, 4}, in fp32 and in the autocast-emulating bf16 mode ("full",
+    ~15 min); the default ("quick") keeps the bench within minutes: one warm-up + median of 3 at B = 1 fp32, one run of
+    bf16 mode.  `value` is always the B = 1 fp32 median."""
+    import statistics
     from oracle import egom2p_oracle as O
     sd = {k: v.detach().float().cpu().clone() for k, v in eng.state_dict().items()}
-    leaf = O.make_leaf_state(sd)
-    one = {k: {kk: vv[:1].clone() for kk, vv in v.items()} for k, v in md_cpu.items()}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("EGOM2P_CPU_THREADS", "16"))))   # the GPU box's CPU share per GPU is 16
     torch.set_num_threads(cores)
-    t0 = time.time()
-    loss, _ = O.forward(leaf, cfg, one, n_enc, n_dec, dec_order=order, mode="fp32")
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": 10300.0 / dt, "unit": "clip-positions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 clip (10300 positions, N=M={n_enc}) fwd+bwd, fp32 oracle, {dt:.1f} s", "loss": float(loss.item())}
+
+    def once(md, mode):
+        leaf = O.make_leaf_state(sd)
+        t0 = time.time()
+        loss, _ = O.forward(leaf, cfg, md, n_enc, n_dec, dec_order=order, mode=mode)
+        loss.backward()
+        return time.time() - t0, float(loss.item())
+
+    plan = ([(1, "fp32", 1, 5), (4, "fp32", 1, 5), (1, "bf16", 1, 5), (4, "bf16", 1, 5)] if protocol == "full"
+            else [(1, "fp32", 1, 3), (1, "bf16", 0, 1)])
+    runs, total = [], 0.0
+    for B, mode, n_warm, n_timed in plan:
+        md = synth.make_clip_batch(cfg, B, budgets, seed=100 + rank, sample_offset=0)      # the GPU run's first clips, host copy
+        for _ in range(n_warm):
+            total += once(md, mode)[0]
+        ts, loss = [], None
+        for _ in range(n_timed):
+            t, loss = once(md, mode)
+            ts.append(t)
+        total += sum(ts)
+        med = statistics.median(ts)
+        runs.append({"batch": B, "mode": mode, "warmup": n_warm, "timed": n_timed, "median_s": round(med, 3),
+                     "clip_positions_per_s": round(B * 10300.0 / med, 1), "loss": loss})
+    head = runs[0]
+    return {"value": head["clip_positions_per_s"], "unit": "clip-positions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"protocol '{protocol}': B=1 fp32 fwd+bwd of one 10300-position clip (N=M={n_enc}), {head['warmup']} warm-up + "
+                      f"median of {head['timed']} ({head['median_s']} s each); all legs {total:.0f} s of CPU work",
+            "loss": head["loss"], "runs": runs}
 
 
 def main():
@@ -64,6 +89,8 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
+                    help="quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; full: SURVEY 8(d) protocol (~15 min)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     args = ap.parse_args()
@@ -71,7 +98,7 @@ def main():
     from egom2p_amd import synth
     from egom2p_amd.config import MODEL_CFGS
     from egom2p_amd.engine import Engine
-    from egom2p_amd.profiler import PEAK_BF16_TFLOPS, KernelTimer
+    from egom2p_amd.profiler import PEAK_BF16_TFLOPS, PEAK_HBM_GBS, KernelTimer, kernel_source_sha
     from egom2p_amd.trainer import TrainStep
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,21 +185,29 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": dom[0], "achieved": dom[1]["tflops"], "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": dom[1]["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
                            "launches": dom[1]["calls"], "avg_launch_ms": dom[1]["ms"] / dom[1]["calls"]}
-        # HBM-side bytes per launch of that kernel: PMC counters need a rocprofv3 wrapper around the process, so they
-        # are collected by the command recorded in profiles/pmc_latest.json (same workload and micro-batch) and read here
+        # HBM-side bytes per launch of that kernel: PMC counters need a rocprofv3 wrapper around the process, so they are
+        # collected by the command recorded in profiles/pmc_latest.json (same workload and micro-batch) and read here -
+        # only while that file was measured on THESE kernels (sha of the kernel sources), else traffic stays null
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             ent = pmc.get("abi", {}).get(dom[0])
-            if ent and pmc.get("micro_batch") == args.micro_batch and args.model == "egom2p_base_12e_12d_swiglu_nobias":
+            same = pmc.get("kernel_src_sha") == kernel_source_sha()
+            if ent and same and pmc.get("micro_batch") == args.micro_batch and args.model == "egom2p_base_12e_12d_swiglu_nobias":
                 out["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/pmc_latest.json)"
-                out["roofline"]["algorithmic_bytes_per_launch"] = dom[1]["bytes"] / dom[1]["calls"]
+            elif ent and not same:
+                out["roofline"]["traffic_note"] = ("profiles/pmc_latest.json was measured on other kernel sources "
+                                                   f"({pmc.get('kernel_src_sha')} vs {kernel_source_sha()}): re-run tools/pmc_run.sh")
+        out["roofline"]["algorithmic_bytes_per_launch"] = dom[1]["bytes"] / dom[1]["calls"]
+        # north_star's HBM-bound paths (embedding / masking / scatter / normalisation / loss): algorithmic GB/s vs the HBM roof
+        hbm = {k: v for k, v in summ.items() if v["flops"] == 0 and v["bytes"] > 0}
+        out["hbm_paths"] = {k: {"gbs": round(v["gbs"], 1), "frac_of_8TBs": round(v["gbs"] / PEAK_HBM_GBS, 3), "us_per_call": round(1e3 * v["ms"] / v["calls"], 1)}
+                            for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}
         out["kernel_breakdown"] = {k: {"ms": round(v["ms"], 3), "calls": v["calls"], "tflops": round(v["tflops"], 1),
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        clip_cpu = synth.make_clip_batch(cfg, 1, budgets, seed=100 + rank, sample_offset=0)      # same first clip, host copy
-        out["cpu_baseline"] = cpu_baseline(cfg, eng, clip_cpu, [m.name for m in cfg.mods], n_enc, n_dec)
+        out["cpu_baseline"] = cpu_baseline(cfg, eng, synth, budgets, rank, [m.name for m in cfg.mods], n_enc, n_dec, args.cpu_baseline)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

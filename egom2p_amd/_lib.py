@@ -51,6 +51,7 @@ _SIGS = {
     "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
+    "ego_gemm_tn_plan": [i32, i32, i32, i64, i64, i64, i32],
     "ego_attn_fwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64,
                          i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
@@ -62,13 +63,12 @@ _SIGS = {
     "ego_gemm_nt_swiglu_fwd": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "ego_ce_fwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp],
     "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp],
-    "ego_loss_finalize": [vp, vp, i32, vp, vp],
+    "ego_loss_finalize": [vp, vp, i32, vp, vp, vp],
     "ego_cast_weight": [vp, i32, i32, i64, vp, i64, vp, i64, i32, vp],
     "ego_cast_f32_bf16": [vp, vp, i64, vp],
     "ego_bias_grad": [vp, i64, i32, vp, vp],
     "ego_grad_sqnorm": [vp, i64, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
-    "ego_grad_scale": [vp, i64, f32, f32, vp, vp],
     "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
 }
 
@@ -101,6 +101,10 @@ def load():
             fn.restype = i32
         if lib.ego_abi_version() != 1:
             raise EgoHipError("libegom2p_hip.so ABI version mismatch")
+        # kernel experiments: EGO_GEMM_NT256 / EGO_GEMM_TN256 = 0 | 1 | 2 pick the GEMM tile family (the library itself
+        # reads no environment; this is the same call tests make through ops.gemm_kernel_mode)
+        if "EGO_GEMM_NT256" in os.environ or "EGO_GEMM_TN256" in os.environ:
+            lib.ego_gemm_kernel_mode(int(os.environ.get("EGO_GEMM_NT256", "1")), int(os.environ.get("EGO_GEMM_TN256", "1")))
         _lib = lib
     return _lib
 
@@ -109,7 +113,3 @@ def check(rc: int, what: str):
     if rc != 0:
         raise EgoHipError(f"{what} failed: {'bad arguments' if rc == 1 else 'kernel launch failed'} (rc={rc})")
 
-
-def tn256_enabled() -> bool:
-    """EGO_GEMM_TN256=0 keeps every wgrad on the 128x128 kernel (read by the library at load time too)."""
-    return os.environ.get("EGO_GEMM_TN256", "1") != "0"

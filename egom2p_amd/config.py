@@ -80,6 +80,8 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     # build-owned
     "ego_tiny_2e_2d": ModelCfg("ego_tiny_2e_2d", 128, 2, 2, 2, modalities=("tok_cam", "tok_gaze")),
     "ego_b_2e_2d": ModelCfg("ego_b_2e_2d", 768, 2, 2, 12),
+    # untied decoder head (`share_embedding=False`, the FM wrapper's setting: egom2p_model.py:856-858) at parity-test depth
+    "ego_b_2e_2d_untied": ModelCfg("ego_b_2e_2d_untied", 768, 2, 2, 12, share_embedding=False),
     "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
     "ego_L_1152_2e_2d": ModelCfg("ego_L_1152_2e_2d", 1152, 2, 2, 18),       # ego-L width (BASELINE config 5) at parity-test depth
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),

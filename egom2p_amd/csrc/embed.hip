@@ -32,103 +32,145 @@ struct CompactArgs {
     int* err;                 // [1] set if the decoder mask is not one interval per row
 };
 
-// one workgroup per sample
-__global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
-    __shared__ int s_cnt[256], s_dam[256], s_mcnt[256], s_mdam[256];
-    __shared__ int s_segstart[EGO_MAX_MODS + 1], s_tot[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int per = (a.T + 255) / 256;
-    const int p0 = tid * per, p1 = min(a.T, p0 + per);
+// CP_SPLIT workgroups per sample, each owning a run of 256-position groups.  A workgroup first sweeps the WHOLE
+// sample's mask / decoder_attention_mask once with coalesced loads (10,300 bytes + 41 KB: the totals and the prefix in
+// front of its own run cost less than a hand-off between workgroups would), then walks its run 256 positions at a
+// time: per wave one ballot gives the rank among the unmasked positions, two 6-step shuffle scans give the running
+// decoder_attention_mask sums among unmasked / masked positions, the four waves are chained through LDS.
+constexpr int CP_SPLIT = 8;
 
-    // modality offsets
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
+    constexpr int NC = 5 + EGO_MAX_MODS;           // pre {cnt, dam unmasked, dam masked}, total {cnt, dam unmasked}, per-modality cnt
+    __shared__ int s_part[4][NC];
+    __shared__ int s_wave[2][4][3];
+    const int b = blockIdx.x / CP_SPLIT, part = blockIdx.x % CP_SPLIT, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int groups = (a.T + 255) >> 8, gper = (groups + CP_SPLIT - 1) / CP_SPLIT;
+    const int c0 = min(a.T, part * gper * 256), c1 = min(a.T, c0 + gper * 256);
+
     int moff[EGO_MAX_MODS + 1];
     moff[0] = 0;
 #pragma unroll
     for (int m = 0; m < EGO_MAX_MODS; ++m) moff[m + 1] = moff[m] + (m < a.n_mods ? a.n_pos[m] : 0);
-
     auto locate = [&](int pos, int& m, int& loc) {
         m = 0;
+        int off = 0;
 #pragma unroll
-        for (int k = 1; k < EGO_MAX_MODS; ++k) if (k < a.n_mods && pos >= moff[k]) m = k;
-        loc = pos - moff[m];
+        for (int k = 1; k < EGO_MAX_MODS; ++k) if (k < a.n_mods && pos >= moff[k]) { m = k; off = moff[k]; }
+        loc = pos - off;
+    };
+    auto fetch = [&](int pos, int& m, int& loc, bool& masked, int& d) {
+        locate(pos, m, loc);
+        const long src = (long)b * a.n_pos[m] + loc;
+        masked = a.mask[m][src] != 0;
+        d = (a.is_decoder && a.dam[m]) ? a.dam[m][src] : 0;
     };
 
-    // pass 1: counts of unmasked positions (and their dam sums) in this thread's range
-    if (tid < EGO_MAX_MODS) s_mcnt[tid] = 0;
-    __syncthreads();
-    int cnt = 0, dsum = 0, mdsum = 0, cur_m = -1, cur_c = 0;
-    for (int pos = p0; pos < p1; ++pos) {
-        int m, loc; locate(pos, m, loc);
-        const bool masked = a.mask[m][(long)b * a.n_pos[m] + loc] != 0;
-        const int d = (a.is_decoder && a.dam[m]) ? a.dam[m][(long)b * a.n_pos[m] + loc] : 0;
-        if (m != cur_m) { if (cur_c) atomicAdd(&s_mcnt[cur_m], cur_c); cur_m = m; cur_c = 0; }
-        if (!masked) { cnt++; cur_c++; dsum += d; } else { mdsum += d; }
-    }
-    if (cur_c) atomicAdd(&s_mcnt[cur_m], cur_c);
-    s_cnt[tid] = cnt; s_dam[tid] = dsum; s_mdam[tid] = mdsum;
-    __syncthreads();
-    // exclusive scans by thread 0..255 (256 values: a serial scan by one wave is plenty here)
-    if (tid == 0) {
-        int c = 0, d = 0, md = 0;
-        for (int i = 0; i < 256; ++i) {
-            const int tc = s_cnt[i], td = s_dam[i], tmd = s_mdam[i];
-            s_cnt[i] = c; s_dam[i] = d; s_mdam[i] = md;
-            c += tc; d += td; md += tmd;
+    // ---- pass 1: whole-sample counts and the prefix in front of this workgroup's run
+    int acc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = 0;
+    for (int pos = tid; pos < a.T; pos += 256) {
+        int m, loc, d; bool masked;
+        fetch(pos, m, loc, masked, d);
+        const bool pre = pos < c0;
+        if (!masked) {
+            acc[3] += 1; acc[4] += d;
+            if (pre) { acc[0] += 1; acc[1] += d; }
+#pragma unroll
+            for (int k = 0; k < EGO_MAX_MODS; ++k) acc[5 + k] += (m == k) ? 1 : 0;
+        } else if (pre) {
+            acc[2] += d;
         }
-        s_tot[0] = c; s_tot[1] = d;
-        // per-slot segment starts among the unmasked rows need per-modality counts: done below
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int v = wave_sum_int(acc[i]);
+        if (lane == 0) s_part[wave][i] = v;
     }
     __syncthreads();
-    const int total_valid = s_tot[0], total_dam = s_tot[1];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = s_part[0][i] + s_part[1][i] + s_part[2][i] + s_part[3][i];
+    const int total_valid = acc[3], total_dam = acc[4];
     const int nv = min(total_valid, a.n_keep);
-    if (tid == 0) a.n_valid[b] = nv;
-
-    // per-modality unmasked counts (s_mcnt) -> segment (start,count) clipped to n_keep
-    if (tid == 0) {
-        int st = 0;
+    int segstart[EGO_MAX_MODS + 1];
+    segstart[0] = 0;
+#pragma unroll
+    for (int m = 0; m < EGO_MAX_MODS; ++m) segstart[m + 1] = segstart[m] + acc[5 + m];
+    if (part == 0 && tid == 0) {
+        a.n_valid[b] = nv;
         for (int m = 0; m < a.n_mods; ++m) {
-            s_segstart[m] = st;
-            const int s0 = min(st, a.n_keep), s1 = min(st + s_mcnt[m], a.n_keep);
+            const int s0 = min(segstart[m], a.n_keep), s1 = min(segstart[m + 1], a.n_keep);
             a.seg[((long)b * a.n_mods + m) * 2] = s0;
             a.seg[((long)b * a.n_mods + m) * 2 + 1] = s1 - s0;
-            st += s_mcnt[m];
         }
-        s_segstart[a.n_mods] = st;
     }
-    __syncthreads();
 
-    // pass 2: scatter
-    int uidx = s_cnt[tid];             // rank among unmasked
-    int dcum = s_dam[tid];             // dam prefix among unmasked (exclusive)
-    int mdcum = s_mdam[tid];           // dam prefix among masked (exclusive)
-    for (int pos = p0; pos < p1; ++pos) {
-        int m, loc; locate(pos, m, loc);
-        const long src = (long)b * a.n_pos[m] + loc;
-        const bool masked = a.mask[m][src] != 0;
-        const int d = (a.is_decoder && a.dam[m]) ? a.dam[m][src] : 0;
-        int out, cs;
-        if (!masked) { out = uidx++; dcum += d; cs = dcum; }
-        else { out = total_valid + (pos - uidx); mdcum += d; cs = total_dam + mdcum; }
-        if (out < a.n_keep) {
-            const long o = (long)b * a.n_keep + out;
-            a.ids_keep[o] = pos;
-            a.pad[o] = masked ? 1 : 0;
-            a.mod_mask[o] = masked ? (short)-1 : (short)a.mod_id[m];
-            a.slot[o] = masked ? -1 : m;
-            a.local[o] = loc;
-            a.tok[o] = masked ? 0 : (int)a.ids[m][src];
-            if (a.is_decoder) {
-                // allowed keys: same modality (ids compared before pads become -1) and j < cumsum(dam)_i.
-                // Same-modality unmasked keys are the contiguous segment [s0, s1).
-                const int s0 = min(s_segstart[m], a.n_keep), s1 = min(s_segstart[m] + s_mcnt[m], a.n_keep);
-                a.ks[o] = s0;
-                a.ke[o] = min(s1, cs);
-                if (cs > nv && nv < a.n_keep) atomicOr(a.err, 1);   // a pad key would be visible: not an interval mask
-            } else {
-                a.ks[o] = 0;
-                a.ke[o] = nv;
+    // ---- pass 2: scatter this workgroup's run
+    int run_cnt = acc[0], run_du = acc[1], run_dm = acc[2];
+    int par = 0;
+    for (int base = c0; base < c1; base += 256, par ^= 1) {
+        const int pos = base + tid;
+        const bool valid = pos < c1;
+        int m = 0, loc = 0, d = 0; bool masked = true;
+        if (valid) fetch(pos, m, loc, masked, d);
+        const bool unm = valid && !masked;
+        const unsigned long long ball = __ballot(unm);
+        const int rank = __popcll(ball & ((1ull << lane) - 1ull));
+        const int du = wave_incl_scan(unm ? d : 0, lane), dm = wave_incl_scan((valid && masked) ? d : 0, lane);
+        if (lane == 63) { s_wave[par][wave][0] = __popcll(ball); s_wave[par][wave][1] = du; s_wave[par][wave][2] = dm; }
+        __syncthreads();
+        int w_cnt = 0, w_du = 0, w_dm = 0, t_cnt = 0, t_du = 0, t_dm = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = s_wave[par][w][0], u = s_wave[par][w][1], q = s_wave[par][w][2];
+            if (w < wave) { w_cnt += c; w_du += u; w_dm += q; }
+            t_cnt += c; t_du += u; t_dm += q;
+        }
+        if (valid) {
+            const int uidx = run_cnt + w_cnt + rank;          // unmasked positions in front of this one
+            int out, cs;
+            if (unm) { out = uidx; cs = run_du + w_du + du; }
+            else { out = total_valid + (pos - uidx); cs = total_dam + run_dm + w_dm + dm; }
+            if (out < a.n_keep) {
+                const long o = (long)b * a.n_keep + out;
+                a.ids_keep[o] = pos;
+                a.pad[o] = masked ? 1 : 0;
+                a.mod_mask[o] = masked ? (short)-1 : (short)a.mod_id[m];
+                a.slot[o] = masked ? -1 : m;
+                a.local[o] = loc;
+                a.tok[o] = masked ? 0 : (int)a.ids[m][(long)b * a.n_pos[m] + loc];
+                if (a.is_decoder) {
+                    // allowed keys: same modality (ids compared before pads become -1) and j < cumsum(dam)_i.
+                    // Same-modality unmasked keys are the contiguous segment [s0, s1).
+                    int sa = 0, sb = 0;
+#pragma unroll
+                    for (int k = 0; k < EGO_MAX_MODS; ++k) if (k == m) { sa = segstart[k]; sb = segstart[k + 1]; }
+                    const int s0 = min(sa, a.n_keep), s1 = min(sb, a.n_keep);
+                    a.ks[o] = s0;
+                    a.ke[o] = min(s1, cs);
+                    if (cs > nv && nv < a.n_keep) atomicOr(a.err, 1);   // a pad key would be visible: not an interval mask
+                } else {
+                    a.ks[o] = 0;
+                    a.ke[o] = nv;
+                }
             }
         }
+        run_cnt += t_cnt; run_du += t_du; run_dm += t_dm;
     }
 }
 
@@ -179,34 +221,44 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 //   perm  [B*M]           row -> grouped row (-1 for pads);  tgt_perm[grouped row] = target id
 //   ranges[n_mods, 2]     (offset, count) of each canonical modality in the grouped order
 // ---------------------------------------------------------------------------------------------
+// Every workgroup rebuilds the small (batch x modality) offset table in LDS (B * n_mods counts: cheaper than a hand-off)
+// and then maps its share of the rows.
 __global__ __launch_bounds__(256) void loss_perm_kernel(const int* __restrict__ seg, const int* __restrict__ canon,
                                                         const int* __restrict__ slot, const int* __restrict__ tok,
                                                         int B, int M, int n_mods, int* __restrict__ perm,
                                                         int* __restrict__ tgt_perm, int* __restrict__ ranges,
-                                                        int* __restrict__ base /* [B, n_mods] scratch */) {
-    __shared__ int s_off[EGO_MAX_MODS + 1];
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int c = 0; c < n_mods; ++c) {          // canonical modality c
-            int sl = 0;
-            for (int s = 0; s < n_mods; ++s) if (canon[s] == c) sl = s;
-            ranges[2 * c] = run;
-            for (int b = 0; b < B; ++b) {
-                base[b * n_mods + sl] = run;
-                run += seg[(b * n_mods + sl) * 2 + 1];
-            }
-            ranges[2 * c + 1] = run - ranges[2 * c];
-        }
-        s_off[0] = run;
+                                                        int* __restrict__ base /* [B, n_mods] (also an output: row offsets) */) {
+    extern __shared__ int lp_sm[];                  // start[B*n_mods] count[B*n_mods] base[B*n_mods] tot[EGO_MAX_MODS]
+    const int nbm = B * n_mods;
+    int* s_start = lp_sm; int* s_cnt = lp_sm + nbm; int* s_base = lp_sm + 2 * nbm; int* s_tot = lp_sm + 3 * nbm;
+    for (int i = threadIdx.x; i < nbm; i += 256) { s_start[i] = seg[2 * i]; s_cnt[i] = seg[2 * i + 1]; }
+    __syncthreads();
+    if (threadIdx.x < n_mods) {                     // total kept rows of decoder slot s over the batch
+        int t = 0;
+        for (int b = 0; b < B; ++b) t += s_cnt[b * n_mods + threadIdx.x];
+        s_tot[threadIdx.x] = t;
     }
     __syncthreads();
-    __threadfence_block();
+    if (threadIdx.x < n_mods) {                     // canonical modality c: rows of all earlier modalities come first
+        const int c = threadIdx.x;
+        int sl = 0, run = 0;
+        for (int s = 0; s < n_mods; ++s) if (canon[s] == c) sl = s;
+        for (int c2 = 0; c2 < c; ++c2)
+            for (int s = 0; s < n_mods; ++s) if (canon[s] == c2) run += s_tot[s];
+        if (blockIdx.x == 0) { ranges[2 * c] = run; ranges[2 * c + 1] = s_tot[sl]; }
+        for (int b = 0; b < B; ++b) {
+            s_base[b * n_mods + sl] = run;
+            if (blockIdx.x == 0) base[b * n_mods + sl] = run;
+            run += s_cnt[b * n_mods + sl];
+        }
+    }
+    __syncthreads();
     const long total = (long)B * M;
-    for (long r = threadIdx.x; r < total; r += 256) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < total; r += (long)gridDim.x * 256) {
         const int s = slot[r];
         if (s < 0) { perm[r] = -1; continue; }
         const int b = (int)(r / M), i = (int)(r % M);
-        const int g = base[b * n_mods + s] + (i - seg[(b * n_mods + s) * 2]);
+        const int g = s_base[b * n_mods + s] + (i - s_start[b * n_mods + s]);
         perm[r] = g;
         tgt_perm[g] = tok[r];
     }
@@ -284,7 +336,7 @@ extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream)
     a.ids_keep = (long long*)d->ids_keep; a.pad = (unsigned char*)d->pad; a.mod_mask = (short*)d->mod_mask;
     a.slot = d->slot; a.local = d->local; a.tok = d->tok; a.ks = d->ks; a.ke = d->ke;
     a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err;
-    EGO_LAUNCH(compact_kernel, dim3(B), dim3(256), 0, stream, a);
+    EGO_LAUNCH(compact_kernel, dim3(B * CP_SPLIT), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -303,7 +355,12 @@ extern "C" int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream) {
 extern "C" int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* tok, int B, int M,
                              int n_mods, int* perm, int* tgt_perm, int* ranges, int* base, hipStream_t stream) {
     if (B <= 0 || M <= 0 || n_mods <= 0 || n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
-    EGO_LAUNCH(loss_perm_kernel, dim3(1), dim3(256), 0, stream, seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base);
+    const size_t lds = ((size_t)3 * B * n_mods + EGO_MAX_MODS) * sizeof(int);
+    if (lds > 48 * 1024) return EGO_ERR_ARG;
+    const long total = (long)B * M;
+    const int blocks = (int)((total + 1023) / 1024 < 256 ? (total + 1023) / 1024 : 256);
+    EGO_LAUNCH(loss_perm_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), lds, stream, seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm,
+               ranges, base);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -17,7 +17,6 @@
 // and their autograd backward (mm dgrad / wgrad).
 #include "common.h"
 #include "egom2p_hip.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -1034,10 +1033,12 @@ __global__ void tn_reduce_kernel(const float* slab, float* C0, float* C1, long l
     }
 }
 
-int g_nt_wgs = 512;        // persistent grid: 2 workgroups (64 KiB LDS each) per CU x 256 CUs
-int g_nt256 = 1;           // use the 256x256 staggered kernel for large shapes (EGO_GEMM_NT256=0 disables)
-int g_tn256 = 1;           // same for the wgrad kernel (EGO_GEMM_TN256=0 disables, 2 forces it where legal)
-long g_tn256_min_area = 512L * 1024L;   // smallest Ni*Nj sent to the 256x256 kernel
+constexpr int NT_WGS = 512;                       // persistent 128x128 grid: 2 workgroups (80 KiB LDS each) per CU x 256 CUs
+constexpr long TN256_MIN_AREA = 512L * 1024L;     // smallest Ni*Nj sent to the 256x256 wgrad kernel
+// The ONLY process-wide state of the library: the tile-family selector of ego_gemm_kernel_mode (a test / tuning hook:
+// 1 = by shape, 0 = 128x128 kernels only, 2 = 256x256 wherever legal) and the one-time "LDS attributes set" latch.
+int g_nt256 = 1;
+int g_tn256 = 1;
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
@@ -1048,11 +1049,11 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
-    if (const char* e = getenv("EGO_GEMM_TN256")) g_tn256 = atoi(e);
-    if (const char* e = getenv("EGO_GEMM_TN256_AREA")) g_tn256_min_area = atol(e);
-    if (const char* e = getenv("EGO_GEMM_NT_WGS")) { const int k = atoi(e); if (k >= 8) g_nt_wgs = k; }
-    if (const char* e = getenv("EGO_GEMM_NT256")) g_nt256 = atoi(e);
     g_attr_done = true;
+}
+
+bool tn256_legal(int Ni, int Nj, long ldp, long ldq) {
+    return (Ni % 128 == 0) && (Nj % 128 == 0) && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
 }
 
 }  // namespace
@@ -1091,7 +1092,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
         return EGO_OK;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < g_nt_wgs ? tiles : g_nt_wgs), dim3(256), NT_LDS, stream, a);
+    EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < NT_WGS ? tiles : NT_WGS), dim3(256), NT_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -1126,6 +1127,21 @@ extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t,
     return EGO_OK;
 }
 
+extern "C" int ego_gemm_tn_plan(int Ni, int Nj, int M, long ldp, long ldq, long slab_elems, int ranged) {
+    // Split-K factor ego_gemm_tn_bf16 should be called with: one full round of workgroups and no more (each split
+    // writes an fp32 [Ni, Nj] slab).  Device-side row ranges are not split (their length is unknown on the host).
+    if (ranged || Ni <= 0 || Nj <= 0 || M <= 0) return 1;
+    const long steps = (M + BK - 1) / BK, cap = slab_elems / ((long)Ni * Nj);
+    long s;
+    if (g_tn256 != 0 && tn256_legal(Ni, Nj, ldp, ldq) && (long)Ni * Nj >= TN256_MIN_AREA)
+        s = 256 / (((Ni + 255) / 256) * ((Nj + 255) / 256));               // 256x256 kernel: one workgroup per CU
+    else
+        s = NT_WGS / (((Ni + BM - 1) / BM) * ((Nj + BN - 1) / BN));        // 128x128 kernel: two per CU
+    s = s < steps ? s : steps;
+    s = s < cap ? s : cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
 extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C0, float* C1, long ldc,
                                 int split_row, int rows0, int rows1, const int* m_range, int Ni, int Nj, int M,
                                 int splits, float* slab, hipStream_t stream) {
@@ -1136,9 +1152,9 @@ extern "C" int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq
     ensure_attrs();
     TNArgs a{(const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, C0, C1, ldc, slab, m_range, split_row, rows0, rows1, Ni, Nj, M, splits};
     // 256x256 staggered kernel, one workgroup per CU
-    const bool legal256 = (Ni % 128 == 0) && (Nj % 128 == 0) && M > 0 && 64L * ldp * 2 < 0x7ff00000L && 64L * ldq * 2 < 0x7ff00000L;
+    const bool legal256 = tn256_legal(Ni, Nj, ldp, ldq);
     const int tiles256 = ((Ni + 255) / 256) * ((Nj + 255) / 256);
-    if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= g_tn256_min_area))) {
+    if (legal256 && (g_tn256 == 2 || (g_tn256 == 1 && tiles256 * splits >= 128 && (long)Ni * Nj >= TN256_MIN_AREA))) {
         EGO_LAUNCH(gemm_tn256_kernel, dim3(tiles256 * splits), dim3(512), NT3_LDS, stream, a);
     } else {
         const int tiles = (Ni / BM) * (Nj / BN);

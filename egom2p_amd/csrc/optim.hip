@@ -63,16 +63,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
 }
 
-// g *= coef (same coefficient as adamw_kernel would use): kept for API parity with clip_grad_norm_
-__global__ void scale_kernel(float* __restrict__ g, long n, float gscale, float max_norm, const double* __restrict__ sqnorm) {
-    float coef = gscale;
-    if (max_norm > 0.f && sqnorm) {
-        const float total = (float)sqrt(*sqnorm) * gscale;
-        coef *= fminf(1.f, max_norm / (total + 1e-6f));
-    }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= coef;
-}
-
 }  // namespace
 
 extern "C" int ego_abi_version(void) { return EGO_ABI_VERSION; }
@@ -98,14 +88,6 @@ extern "C" int ego_adamw_step(float* p, float* g, float* m, float* v, long n, fl
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     EGO_LAUNCH(adamw_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, p, g, m, v, n, lr, wd, beta1, beta2, eps,
                        bc1, bc2s, gscale, max_norm, sqnorm, zero_grad);
-    LAUNCH_CHECK();
-    return EGO_OK;
-}
-
-extern "C" int ego_grad_scale(float* g, long n, float gscale, float max_norm, const double* sqnorm, hipStream_t stream) {
-    if (n <= 0) return EGO_OK;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    EGO_LAUNCH(scale_kernel, dim3(blocks), dim3(256), 0, stream, g, n, gscale, max_norm, sqnorm);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -297,33 +297,80 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits
 }
 
 // mod_loss[m] = sum(nll[off..off+n)) / n (0 if n == 0); loss = sum_m mod_loss / n_mods.  One block.
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ nll, const int* __restrict__ ranges,
-                                                            int n_mods, float* __restrict__ out) {
-    __shared__ float red[4];
+// One workgroup of 1024 threads, 4 independent 16-byte loads in flight per thread: the 65,536 per-row losses of a
+// micro-batch (256 KB) are four round trips, and the sum order is fixed (bitwise reproducible).  `err` (optional): the
+// compaction's "decoder mask is not an interval" flag - a set flag poisons the loss (NaN: the train loop's non-finite
+// check then stops the run like the reference's, run_training_egom2p.py:731-734) and is cleared for the next step.
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ nll, const int* __restrict__ ranges,
+                                                             int n_mods, float* __restrict__ out, int* __restrict__ err) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
     float total = 0.f;
     for (int m = 0; m < n_mods; ++m) {
         const int off = ranges[2 * m], n = ranges[2 * m + 1];
-        float s = 0.f;
-        for (int i = threadIdx.x; i < n; i += 256) s += nll[off + i];
-        s = wave_sum(s);
+        const float* p = nll + off;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int head = min(n, (int)((4 - (off & 3)) & 3));       // up to the first 16-byte boundary
+        if (tid < head) s0 += p[tid];
+        const int n4 = (n - head) >> 2;
+        const f32x4* p4 = (const f32x4*)(p + head);
+        int i = tid;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const f32x4 a = p4[i], b = p4[i + 1024], c = p4[i + 2048], d = p4[i + 3072];
+            s0 += (a[0] + a[1]) + (a[2] + a[3]); s1 += (b[0] + b[1]) + (b[2] + b[3]);
+            s2 += (c[0] + c[1]) + (c[2] + c[3]); s3 += (d[0] + d[1]) + (d[2] + d[3]);
+        }
+        for (; i < n4; i += 1024) { const f32x4 a = p4[i]; s0 += (a[0] + a[1]) + (a[2] + a[3]); }
+        const int tail0 = head + 4 * n4;
+        if (tail0 + tid < n) s1 += p[tail0 + tid];
+        float s = wave_sum((s0 + s1) + (s2 + s3));
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        if ((tid & 63) == 0) red[tid >> 6] = s;
         __syncthreads();
-        const float ml = n > 0 ? (red[0] + red[1] + red[2] + red[3]) / (float)n : 0.f;
-        if (threadIdx.x == 0) out[1 + m] = ml;
+        float r = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) r += red[w];
+        const float ml = n > 0 ? r / (float)n : 0.f;
+        if (tid == 0) out[1 + m] = ml;
         total += ml;
     }
-    if (threadIdx.x == 0) out[0] = total / (float)n_mods;
+    if (tid == 0) {
+        float v = total / (float)n_mods;
+        if (err && *err) {
+            v = __int_as_float(0x7fc00000);
+            for (int m = 0; m < n_mods; ++m) out[1 + m] = v;
+            *err = 0;
+        }
+        out[0] = v;
+    }
 }
 
-// db[col] += sum_rows g[row][col]   (bf16 g, fp32 accumulate)
+// db[col] += sum_rows g[row][col]   (bf16 g, fp32 accumulate).  A workgroup owns 256 rows; a thread sums 8 adjacent columns
+// (one 16-byte load per row) of every (256 / (D / 8))-th row, the row groups are combined in LDS, one atomic per column
+// and workgroup.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ g, long rows, int D, float* __restrict__ db) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= D) return;
-    const long r0 = (long)blockIdx.y * 256, r1 = min(rows, r0 + 256);
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += bf16_to_f32(g[r * D + col]);
-    atomicAdd(db + col, s);
+    extern __shared__ __attribute__((aligned(16))) float bg_sm[];      // [rgroups][D]
+    const int nvec = D >> 3, rgroups = 256 / nvec;
+    const int cv = threadIdx.x % nvec, rg = threadIdx.x / nvec;
+    const long r0 = (long)blockIdx.x * 256, r1 = min(rows, r0 + 256);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (rg < rgroups) {
+        for (long r = r0 + rg; r < r1; r += rgroups) {
+            const u32x4 v = *(const u32x4*)(g + r * D + cv * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16_to_f32(v[e] & 0xffff); acc[2 * e + 1] += bf16_to_f32(v[e] >> 16); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bg_sm[rg * D + cv * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < rgroups; ++q) s += bg_sm[q * D + c];
+        atomicAdd(db + c, s);
+    }
 }
 
 // dst_bf16 = src_f32 (flat)
@@ -414,16 +461,19 @@ extern "C" int ego_ce_bwd(void* logits, long ld, int V, const int* targets, cons
     return EGO_OK;
 }
 
-extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream) {
-    if (n_mods <= 0) return EGO_ERR_ARG;
-    EGO_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, nll, ranges, n_mods, out);
+extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, hipStream_t stream) {
+    if (n_mods <= 0 || n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
+    EGO_LAUNCH(loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, nll, ranges, n_mods, out, err);
     LAUNCH_CHECK();
     return EGO_OK;
 }
 
 extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    EGO_LAUNCH(bias_grad_kernel, dim3((D + 255) / 256, (int)((rows + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)g, rows, D, db);
+    if (D % 8 || D > 2048 || (((uintptr_t)g) & 15)) return EGO_ERR_ARG;
+    const int rgroups = 256 / (D / 8);
+    EGO_LAUNCH(bias_grad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)rgroups * D * sizeof(float), stream,
+               (const bf16_t*)g, rows, D, db);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -78,11 +78,6 @@ class GradBucketReducer:
         self._works.clear()
         self.last_launched, self.launched = self.launched, []
 
-    def reduce_all(self):
-        """Un-overlapped fallback: one all-reduce over the whole buffer."""
-        if self.world > 1:
-            dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.pg)
-
 
 class DataParallel(torch.nn.Module):
     """DDP-shaped wrapper for `egom2p_amd.model.EgoM2P` (`.module`, `no_sync()`, forward passthrough)."""

@@ -64,6 +64,8 @@ class Engine:
         self._alloc_workspaces()
         self.weights_dirty = True
         self._have_fwd = False
+        self.max_graphs = 16                  # captured generation passes kept alive at once (LRU)
+        self._iw, self._infer_key = None, None
         # optional: weight-gradient GEMMs on a side stream beside the dgrad / attention chain of the same layer, joined
         # at every bucket boundary.  Measured on MI355X: parity-clean but 5 % SLOWER than one stream (the co-running
         # kernels fight for LDS / L2), so it is off by default (EGOM2P_WGRAD_STREAM=1 enables it).
@@ -149,8 +151,13 @@ class Engine:
         starts = [offs[spec[i][0]][0] for _, i in marks] + [total]
         self.buckets = [(marks[i][0], starts[i], starts[i + 1]) for i in range(len(marks))]
         # optimiser runs: contiguous ranges of equal weight-decay class (no_decay: norm weights and biases)
+        # tensors no kernel ever writes a gradient for: with an untied head the decoder token tables are never read (the
+        # decoder rows are the mask token, egom2p_model.py:328), the reference leaves their .grad None and AdamW skips them
+        self.never_grad = set() if cfg.share_embedding else {f"decoder_embeddings.{m.name}.token_emb.weight" for m in self.mods}
         runs: List[List] = []
         for name, shape in spec:
+            if name in self.never_grad:
+                continue
             o, n, _ = offs[name]
             nd = ("norm." in name or ".norm" in name or name.endswith(".bias"))
             n4 = (n + 3) // 4 * 4
@@ -209,13 +216,20 @@ class Engine:
             return t[:, :F]
         return t
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> List[str]:
+        """Copies every known entry into the flat buffer; returns the keys this engine has no storage for (the module's
+        `load_state_dict` reports them as unexpected / raises under strict=True)."""
+        unexpected = []
         for key, val in sd.items():
-            v = self._view_for_key(key)
-            if v is None:
+            if key.endswith("pos_emb") or (key.endswith(".bias") and "norm" in key):
+                continue                                  # buffers: pos tables are rebuilt, LN bias is a zero buffer
+            if self._canon_key(key) not in self.p:
+                unexpected.append(key)
                 continue
+            v = self._view_for_key(key)
             v.copy_(val.to(self.dev, F32).reshape(v.shape))
         self.weights_dirty = True
+        return unexpected
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}
@@ -259,13 +273,20 @@ class Engine:
     @torch.no_grad()
     def init_random(self, seed: int = 0):
         """Random init in the reference's distributions (egom2p_model.py:185-222), drawn on the device:
-        xavier-uniform linears (qkv / kv as 3 / 2 matrices), N(0, 0.02) embeddings, LayerNorm weight 1."""
+        xavier-uniform linears (qkv / kv as 3 / 2 matrices), N(0, 0.02) encoder tables / mod_emb / mask_token,
+        LayerNorm weight 1.  The `to_logits` operand - the tied decoder table when `share_embedding` is set
+        (decoder_embeddings.py:447-449: token_emb and to_logits are one tensor and the Linear is initialised last) -
+        is xavier-uniform on its [V, D] shape."""
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(seed)
         self.P.zero_()
+        logit_keys = set(self.logit_key.values())
         for name in self.p:
             v = self._view_for_key(name)
-            if name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token" or name.endswith("to_logits.weight"):
+            if name in logit_keys:
+                a = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
+                v.copy_((torch.rand(v.shape, device=self.dev, generator=gen) * 2 - 1) * a)
+            elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token":
                 v.copy_(torch.randn(v.shape, device=self.dev, generator=gen) * 0.02)
             elif name.endswith("norm.weight") or ".norm" in name:
                 v.fill_(1.0)
@@ -390,7 +411,7 @@ class Engine:
 
     def _wgrad(self, G, dY, X, Ni, Nj, rows, ldp, ldq, m_range=None):
         """G[Ni,Nj] += dY^T X on the side stream (operands must stay untouched until the next _join_side)."""
-        splits = ops.tn_splits(Ni, Nj, rows, self.slab.numel(), ranged=m_range is not None)
+        splits = ops.tn_splits(Ni, Nj, rows, self.slab.numel(), ranged=m_range is not None, ldp=ldp, ldq=ldq)
 
         def run():
             ops.gemm_tn(dY, X, G, Ni, Nj, rows, m_range=m_range, splits=splits, slab=self.slab if splits > 1 else None,
@@ -463,7 +484,9 @@ class Engine:
             nxt = self.enc[i + 1]["x"] if i + 1 < cfg.encoder_depth else self.x_enc_out
             ops.layernorm_fwd(w["x"][:RN], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
             self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln1"], w["qkv"], RN)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], ce["ks"], ce["ke"], N, 1, B, N, N)
+            # key-padding mask = one interval [0, n_valid) per SAMPLE (the per-row copies ce["ks"/"ke"] hold the same
+            # numbers): the uniform form lets the attention kernels walk one (batch, head) pair per XCD (L2-resident K / V)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N)
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
             ops.layernorm_fwd(w["xm"][:RN], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
             self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RN)
@@ -504,7 +527,8 @@ class Engine:
             lg = self.logits[m.vocab_size]
             ops.gemm_nt(self.yn, l.wb, lg, ub, m.vocab_size, D, L.EPI_BF16, m_range=self.ranges[c], lda=D, ldb=D, ldc=m.vocab_size)
             ops.ce_fwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll)
-        ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out)
+        # a decoder_attention_mask that is not one interval per row (compaction flag) turns the loss into NaN
+        ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out, err=cd["err"])
         return self.loss_out[0], {m.name: self.loss_out[1 + c] for c, m in enumerate(mods)}
 
     # ------------------------------------------------------------------------------------ backward
@@ -526,11 +550,12 @@ class Engine:
                           dx_in=dres, dx_bf16=nb)
         return nb
 
-    def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke):
+    def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke, r_bs=None, r_rs=1):
         D, B = self.D, self.B
+        r_bs = Nq if r_bs is None else r_bs
         dao, dqkv, dln = self.t_d, self.t_3d, self.t_d2
         self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
-        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, Nq, 1, B, Nq, Nq)
+        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq)
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
@@ -616,7 +641,7 @@ class Engine:
         for i in reversed(range(cfg.encoder_depth)):
             w, pre = self.enc[i], f"encoder.{i}"
             dxe_b = self._mlp_bwd(pre, w, dxe, dxe_b, RN, w["xm"])
-            dxe_b = self._self_attn_bwd(pre, "attn", w, dxe, dxe_b, RN, N, ce["ks"], ce["ke"])
+            dxe_b = self._self_attn_bwd(pre, "attn", w, dxe, dxe_b, RN, N, self.zero_b, ce["n_valid"], r_bs=1, r_rs=0)
             done(pre)
         # encoder input embeddings: token rows, mod_emb (emb is used twice: x = tok + emb and context += emb)
         ops.embed_bwd([self.g[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
@@ -636,13 +661,22 @@ class Engine:
         self.Bmax, self.N, self.M = max_batch, n_enc, n_dec
         self._alloc_workspaces()
         self._have_fwd = False
+        self.drop_graphs()
+
+    def drop_graphs(self):
+        """Forget every captured generation graph (and the workspace it owns).  A hipGraph bakes device addresses in: it
+        is only valid while the buffers it was captured against are alive, so anything that re-allocates engine memory
+        calls this.  (Round 1 hit exactly that: a graph captured against a shared inference workspace replayed after a
+        larger pass had re-allocated it -> GPU memory access fault; since then each graph owns its workspace.)"""
+        self.__dict__.pop("_graphs", None)
+        self._iw, self._infer_key = None, None
 
     # ------------------------------------------------------------------------------------ generation (config 4)
     def _alloc_infer(self, B: int, Nmax: int, Mmax: int, fresh: bool = False):
         """One set of buffers (nothing is saved for a backward) for encoder-decoder passes of the ROAR / CFG
         generation path, sized for up to Nmax encoder rows and Mmax decoder rows per sample."""
         key = (B, Nmax, Mmax)
-        if not fresh and getattr(self, "_infer_key", None) is not None and all(a >= b for a, b in zip(self._infer_key, key)):
+        if not fresh and self._infer_key is not None and all(a >= b for a, b in zip(self._infer_key, key)):
             return self._iw
         D, Fp, H, dev = self.D, self.Fp, self.H, self.dev
         R = B * max(Nmax, Mmax)
@@ -694,7 +728,6 @@ class Engine:
             ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
                           [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
                           x, w["emb"], RN, D)
-            Ns = side["ks"].shape[1]                    # row stride of the side buffers (allocated for Nmax)
             for i in range(cfg.encoder_depth):
                 pre = f"encoder.{i}"
                 ops.layernorm_fwd(x[:RN], self.p[f"{pre}.norm1.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
@@ -751,8 +784,14 @@ class Engine:
         names = tuple(m.name for m in self.mods if m.name in enc_inputs)
         key = (B, names, int(n_enc), M, target)
         graphs = self.__dict__.setdefault("_graphs", {})
-        g = graphs.get(key)
+        g = graphs.pop(key, None)
+        if g is not None:
+            graphs[key] = g                                # most recently used last
         if g is None:
+            # every graph owns a workspace of ~30 KB per row: bound the cache (a ROAR schedule needs 2 x steps shapes;
+            # the least recently used graph and its buffers are released first)
+            while len(graphs) >= self.max_graphs:
+                graphs.pop(next(iter(graphs)))
             V = {m.name: m for m in self.mods}[target].vocab_size
             # a captured graph bakes in device addresses: it owns its workspace for as long as it lives
             st = {"ws": self._alloc_infer(B, max(int(n_enc), 1), M, fresh=True),
@@ -784,6 +823,10 @@ class Engine:
         """`return_logits=True` path of EgoM2P.forward (egom2p_model.py:727-729, 546-547): logits of every
         decoder row for every modality, (B, M, V) bf16."""
         self.forward(mod_dict, dec_order=dec_order, need_loss=False, group_rows=False)
+        if int(self.cd["err"].item()):              # inference API: the caller reads the logits on the host anyway
+            self.cd["err"].zero_()
+            raise L.EgoHipError("decoder_attention_mask is not one key interval per row (egom2p_model.py:446-481 would "
+                                "produce a mask this engine cannot express)")
         B, M, D = self.B, self.M, self.D
         out = {}
         for m in self.mods:

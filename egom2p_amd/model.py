@@ -247,11 +247,24 @@ class EgoM2P(nn.Module):
 
     # ---- reference API --------------------------------------------------------------------------
     def init_weights(self):
-        """MAE-style init of the reference (egom2p_model.py:185-222), drawn on the device."""
+        """MAE-style init of the reference (egom2p_model.py:185-222), drawn on the device.
+
+        `named_modules()` of the reference visits `decoder_embeddings.X.token_emb` (Embedding: N(0, 0.02)) and then
+        `decoder_embeddings.X.to_logits` (Linear: xavier-uniform on [V, D]); with `share_embedding` both are ONE
+        tensor (decoder_embeddings.py:447-449), so the tied decoder table ends up xavier-uniform."""
         import math
-        for name, p in self.named_parameters():
+        tied = self.cfg.share_embedding
+        seen = set()
+        for name, p in self.named_parameters(remove_duplicate=False):
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            dec_table = name.startswith("decoder_embeddings") and name.endswith(("token_emb.weight", "to_logits.weight"))
             with torch.no_grad():
-                if name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token":
+                if dec_table and (tied or name.endswith("to_logits.weight")):
+                    a = math.sqrt(6.0 / float(p.shape[0] + p.shape[1]))
+                    p.uniform_(-a, a)
+                elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token":
                     p.normal_(0, self.init_std)
                 elif "norm" in name and name.endswith(".weight") and p.dim() == 1:
                     p.fill_(1.0)
@@ -274,7 +287,7 @@ class EgoM2P(nn.Module):
         return set()
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        self.engine.load_state_dict(state_dict)
+        self.engine.load_state_dict(state_dict)              # skips (and returns) keys it has no storage for
         own = set(self.state_dict().keys())
         missing = [k for k in own if k not in state_dict]
         unexpected = [k for k in state_dict if k not in own]

@@ -78,19 +78,11 @@ def clip_synth(key_ids, key_perm, k_in, k_tgt, n, vocab, ids, input_mask, target
 def gemm_kernel_mode(nt256=1, tn256=1):
     """1 = tile family by shape (default), 0 = 128x128 kernels only, 2 = 256x256 wherever legal"""
     check(L.load().ego_gemm_kernel_mode(nt256, tn256), "ego_gemm_kernel_mode")
-    os.environ["EGO_GEMM_TN256"] = str(tn256)          # tn_splits mirrors the launcher's choice
 
 
-def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, wgs128=512, wgs256=256):
-    """Split-K factor for `gemm_tn`: one full round of workgroups and no more.  Large whole-step shapes run on the
-    256x256 kernel (1 workgroup per CU), the rest on the 128x128 kernel (2 per CU); mirrors the launcher's choice."""
-    if ranged:
-        return 1
-    steps = max(1, (rows + 63) // 64)
-    cap = max(1, slab_numel // (Ni * Nj))
-    if Ni % 128 == 0 and Nj % 128 == 0 and Ni * Nj >= int(os.environ.get("EGO_GEMM_TN256_AREA", 512 * 1024)) and L.tn256_enabled():
-        return max(1, min(steps, wgs256 // (((Ni + 255) // 256) * ((Nj + 255) // 256)), cap))
-    return max(1, min(steps, wgs128 // ((Ni // 128) * (Nj // 128)), cap))
+def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
+    """Split-K factor for `gemm_tn`, asked from the launcher itself (ego_gemm_tn_plan)."""
+    return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))
 
 
 def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):
@@ -150,8 +142,8 @@ def ce_bwd(logits, ld, V, targets, rng, max_rows, lse, gscale, n_mods):
           "ego_ce_bwd")
 
 
-def loss_finalize(nll, ranges, n_mods, out):
-    check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _stream()), "ego_loss_finalize")
+def loss_finalize(nll, ranges, n_mods, out, err=None):
+    check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _p(err), _stream()), "ego_loss_finalize")
 
 
 def cast_weight(W, Wb=None, Wt=None, rows_dst=None, ld_w=None, ld_t=None):
@@ -179,10 +171,6 @@ def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.95, eps=1e-8, gscale
                zero_grad=False):
     check(L.load().ego_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, wd, beta1, beta2, eps, step, gscale, max_norm,
                                   _p(sqnorm), int(zero_grad), _stream()), "ego_adamw_step")
-
-
-def grad_scale(g, gscale, max_norm, sqnorm):
-    check(L.load().ego_grad_scale(_p(g), g.numel(), gscale, max_norm, _p(sqnorm), _stream()), "ego_grad_scale")
 
 
 def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_pos, mod_ids, n_keep, is_decoder, out, B):

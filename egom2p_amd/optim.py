@@ -43,6 +43,7 @@ class FusedAdamW:
         ]
         self._frozen_sig = None
         self._runs = list(engine.opt_runs)
+        self._frozen_ranges: List = []          # [lo, hi) ranges of the flat buffers that belong to frozen tensors
         self.last_grad_norm: Optional[torch.Tensor] = None
 
     def _active_runs(self):
@@ -54,19 +55,25 @@ class FusedAdamW:
             self._frozen_sig = sig
             if all(sig):
                 self._runs = list(self.engine.opt_runs)
+                self._frozen_ranges = []
             else:
-                eng, runs = self.engine, []
-                frozen = {eng._canon_key(n) for (n, p) in self._named if not p.requires_grad}
+                eng, runs, fro = self.engine, [], []
+                frozen = {eng._canon_key(n) for (n, p) in self._named if not p.requires_grad} | set(eng.never_grad)
                 for name, (o, n, _) in eng.offsets.items():
-                    if name in frozen:
-                        continue
                     n4 = (n + 3) // 4 * 4
+                    if name in frozen:
+                        if fro and fro[-1][1] == o:
+                            fro[-1][1] = o + n4
+                        else:
+                            fro.append([o, o + n4])
+                        continue
                     nd = is_no_decay(name)
                     if runs and runs[-1][2] == nd and runs[-1][1] == o:
                         runs[-1][1] = o + n4
                     else:
                         runs.append([o, o + n4, nd])
                 self._runs = [tuple(r) for r in runs]
+                self._frozen_ranges = [tuple(r) for r in fro]
         return self._runs
 
     @torch.no_grad()
@@ -77,12 +84,22 @@ class FusedAdamW:
         self.t += 1
         gscale = 1.0 / self.world_size
         norm = None
+        runs = self._active_runs()
         if clip_grad is not None:
+            # clip_grad_norm_ of the reference (native_scaler.py:33) sees only tensors that have a gradient: the engine's
+            # backward writes every tensor's gradient, so frozen ranges are left out of the norm here
             self.sqnorm.zero_()
-            ops.grad_sqnorm(eng.G, self.sqnorm)
+            if not self._frozen_ranges:
+                ops.grad_sqnorm(eng.G, self.sqnorm)
+            else:
+                for lo, hi, _ in runs:
+                    ops.grad_sqnorm(eng.G[lo:hi], self.sqnorm)
             norm = self.sqnorm.sqrt().to(torch.float32) * gscale
+        if zero_grad:
+            for lo, hi in self._frozen_ranges:      # never consumed: must not accumulate from step to step
+                eng.G[lo:hi].zero_()
         decay, nodecay = self.param_groups
-        for lo, hi, nd in self._active_runs():
+        for lo, hi, nd in runs:
             grp = nodecay if nd else decay
             ops.adamw_step(eng.P[lo:hi], eng.G[lo:hi], self.m[lo:hi], self.v[lo:hi], float(grp["lr"]), float(grp["weight_decay"]),
                            self.t, self.betas[0], self.betas[1], self.eps, gscale=gscale,

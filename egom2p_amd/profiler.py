@@ -17,6 +17,20 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s achievable)
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources the in-tree library is built from: ties a committed PMC summary
+    (profiles/pmc_latest.json) to the kernels it was measured on."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(f for f in os.listdir(os.path.join(root, "csrc")) if f.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(root, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def detail_names() -> bool:
     import os
     return os.environ.get("EGOM2P_PROFILE_DETAIL") == "1"
@@ -111,17 +125,53 @@ class KernelTimer:
             "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
             "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
         }
-        other = ["compact", "embed_fwd", "embed_bwd", "loss_perm", "loss_finalize", "cast_weight", "cast_f32_bf16",
-                 "bias_grad", "grad_sqnorm", "adamw_step"]
+        # HBM-bound front-end / bookkeeping kernels: algorithmic bytes (the index streams once, only
+        # the kept rows of the tables / positional tables, every output once)
+        def c_compact(masks, ids, dams, n_pos, mod_ids, n_keep, is_decoder, out, B):
+            T = sum(n_pos)
+            return 0.0, float(B) * (T * (1 + (4 if is_decoder else 0)) + n_keep * (8 + 31))
+
+        def c_embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D):
+            n_rw = (1 if tables is not None else 0) + 1 + 1 + (1 if emb is not None else 0)   # token row, pos row | x, emb
+            return 0.0, float(rows) * D * 4 * n_rw + rows * 12.0
+
+        def c_embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D):
+            n_rw = 1 + (1 if d2 is not None else 0) + (1 if dtables is not None else 0)       # dx, d2 | table rows (atomic adds)
+            return 0.0, float(rows) * D * 4 * n_rw + rows * 8.0
+
+        def c_loss_perm(seg, canon, slot, tok, B, M, n_mods, *a):
+            return 0.0, float(B) * M * 16.0
+
+        def c_loss_finalize(nll, ranges, n_mods, out, err=None):
+            return 0.0, float(ranges[:n_mods, 1].sum().item()) * 4.0
+
+        def c_cast_weight(W, Wb=None, Wt=None, **kw):
+            return 0.0, float(W.numel()) * (4 + (2 if Wb is not None else 0) + (2 if Wt is not None else 0))
+
+        def c_cast(src, dst):
+            return 0.0, float(src.numel()) * 6.0
+
+        def c_bias_grad(g, rows, D, db):
+            return 0.0, float(rows) * D * 2.0
+
+        def c_sqnorm(g, out):
+            return 0.0, float(g.numel()) * 4.0
+
+        def c_adamw(p, g, m, v, *a, zero_grad=False, **kw):
+            return 0.0, float(p.numel()) * (16 + 12 + (4 if zero_grad else 0))
+
+        other = {"compact": c_compact, "embed_fwd": c_embed_fwd, "embed_bwd": c_embed_bwd, "loss_perm": c_loss_perm,
+                 "loss_finalize": c_loss_finalize, "cast_weight": c_cast_weight, "cast_f32_bf16": c_cast, "bias_grad": c_bias_grad,
+                 "grad_sqnorm": c_sqnorm, "adamw_step": c_adamw}
         saved = {}
         # the fused launches are the same device kernel (gemm_nt256_kernel<EK>) behind other entry points: one class
         family = {"gemm_nt_swiglu_fwd": "gemm_nt", "gemm_nt_swiglu_bwd": "gemm_nt"}
         for name, cost in table.items():
             saved[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(family.get(name, name) if not detail_names() else name, saved[name], cost))
-        for name in other:
+        for name, cost in other.items():
             saved[name] = getattr(ops, name)
-            setattr(ops, name, self._wrap("other:" + name, saved[name], lambda *a, **k: (0.0, 0.0)))
+            setattr(ops, name, self._wrap("other:" + name, saved[name], cost))
         try:
             yield self
         finally:

@@ -4,8 +4,9 @@
  * nn.Module surface of `EgoM2P` (egom2p/models/egom2p_model.py:57-734).  These entry points are what
  * sits under that surface here: plain C functions over raw device pointers, explicit shapes/strides
  * and a hipStream_t.  They return 0 on success (EGO_ERR_ARG = rejected arguments, EGO_ERR_LAUNCH =
- * launch failed), never allocate caller-visible memory, never synchronise, and keep no global state,
- * so every call is capturable in a hipGraph and re-entrant per stream.
+ * launch failed), never allocate caller-visible memory and never synchronise, so every call is capturable
+ * in a hipGraph and re-entrant per stream.  The library reads no environment variables; its only process-wide
+ * state is the GEMM tile-family selector set by ego_gemm_kernel_mode (a test / tuning hook, default "by shape").
  *
  * Each declaration cites the reference code it replaces (paths relative to the reference root).
  * All "bf16" pointers are raw 16-bit bfloat16; "row-major [R, C] with ld" means element (r, c) at
@@ -116,6 +117,11 @@ int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C0
                      int rows0, int rows1, const int* m_range, int Ni, int Nj, int M, int splits, float* slab,
                      hipStream_t stream);
 
+/* Split-K factor `splits` the wgrad above should be called with for this shape (>= 1; 1 when the row range lives on the
+ * device): one round of workgroups, bounded by the slab the caller owns (slab_elems fp32).  The launcher's own rule -
+ * the host never mirrors it. */
+int ego_gemm_tn_plan(int Ni, int Nj, int M, long ldp, long ldq, long slab_elems, int ranged);
+
 /* Fused attention, head_dim 64 (Attention / CrossAttention, egom2p_utils.py:185-205, 222-244).
  * Element (b, row, head h, d) of X at X + b * x_bs + row * x_rs + h * 64 + d.  ks/ke: allowed key
  * interval of query row (b, q) at [b * r_bs + q * r_rs] (r_rs = 0: one interval per sample).
@@ -163,8 +169,10 @@ int ego_ce_fwd(const void* logits, long ld, int V, const int* targets, const int
                float* nll, hipStream_t stream);
 int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, const float* lse,
                const float* gscale, int n_mods, hipStream_t stream);
-/* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality. */
-int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, hipStream_t stream);
+/* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality.
+ * err (optional): ego_compact's flag word; if set, every output is NaN (the reference's non-finite-loss exit,
+ * run_training_egom2p.py:731-734, then stops the run instead of training on a wrong attention mask) and it is cleared. */
+int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, hipStream_t stream);
 
 /* ---- generation (config 4) ------------------------------------------------------------------- */
 
@@ -189,7 +197,6 @@ int ego_bias_grad(const void* g_bf16, long rows, int D, float* db, hipStream_t s
 int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t stream);
 int ego_adamw_step(float* p, float* g, float* m, float* v, long n, float lr, float wd, float beta1, float beta2, float eps,
                    int step, float gscale, float max_norm, const double* sqnorm, int zero_grad, hipStream_t stream);
-int ego_grad_scale(float* g, long n, float gscale, float max_norm, const double* sqnorm, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -66,10 +66,11 @@ def build_reference_model(cfg, enc, dec, model):
         info[m.name] = {"vocab_size": m.vocab_size, "max_tokens": m.max_tokens, "type": m.type, "id": m.id}
         if m.kind == "video":
             e_emb[m.name] = enc.VideoTokenEncoderEmbedding(vocab_size=m.vocab_size, patch_size=(4, 8, 8), image_size=256)
-            d_emb[m.name] = dec.VideoTokenDecoderEmbedding(vocab_size=m.vocab_size, patch_size=(4, 8, 8), image_size=256)
+            d_emb[m.name] = dec.VideoTokenDecoderEmbedding(vocab_size=m.vocab_size, patch_size=(4, 8, 8), image_size=256,
+                                                           share_embedding=cfg.share_embedding)
         else:
             e_emb[m.name] = enc.GazeCamTokenEncoderEmbedding(vocab_size=m.vocab_size)
-            d_emb[m.name] = dec.GazeCamTokenDecoderEmbedding(vocab_size=m.vocab_size)
+            d_emb[m.name] = dec.GazeCamTokenDecoderEmbedding(vocab_size=m.vocab_size, share_embedding=cfg.share_embedding)
     net = model.EgoM2P(
         encoder_embeddings=e_emb, decoder_embeddings=d_emb, modality_info=info,
         dim=cfg.dim, encoder_depth=cfg.encoder_depth, decoder_depth=cfg.decoder_depth,
@@ -85,6 +86,7 @@ GRAD_TAPS_B = [
     "encoder_embeddings.tok_rgb.mod_emb", "encoder_embeddings.tok_cam.mod_emb",
     "mask_token", "decoder_proj_context.bias", "decoder_proj_context.weight", "encoder_norm.weight",
     "decoder_norm.weight",
+    "decoder_embeddings.tok_rgb.to_logits.weight", "decoder_embeddings.tok_gaze.to_logits.weight",   # untied head only
 ]
 
 
@@ -204,7 +206,7 @@ def run_case(case, cfg_name, batch, n_enc, n_dec, budgets, seed, full_float, py_
     named = dict(net.named_parameters())
     total_sq = sum(p.grad.double().pow(2).sum().item() for p in named.values() if p.grad is not None)
     gold["grad_total_norm"] = np.array(total_sq ** 0.5)
-    names = [n for n in (GRAD_TAPS_TINY if full_float else GRAD_TAPS_B) if n in named]
+    names = [n for n in (GRAD_TAPS_TINY if full_float else GRAD_TAPS_B) if n in named and named[n].grad is not None]
     # one scalar per trainable tensor: catches an error in any gradient without storing them all
     gold["grad_names"] = np.array(list(named.keys()))
     gold["grad_sqnorm_all"] = np.array([named[n].grad.double().pow(2).sum().item() if named[n].grad is not None
@@ -258,10 +260,36 @@ CASES = {
     # ego-L width (D = 1152, 18 heads of 64, F = 3072: BASELINE config 5), 2+2 layers, canonical split, B=1
     "L2": dict(cfg_name="ego_L_1152_2e_2d", batch=1, n_enc=2048, n_dec=2048, budgets=None, seed=6,
                full_float=False, py_seed=16),
+    # ego-b width, 2+2 layers, UNTIED to_logits (share_embedding=False: decoder_embeddings.py:447-449 not taken), B=1
+    "b2_untied": dict(cfg_name="ego_b_2e_2d_untied", batch=1, n_enc=2048, n_dec=2048, budgets=None, seed=7,
+                      full_float=False, py_seed=17),
     # full-depth ego-b (400M), canonical split, B=1
     "b12": dict(cfg_name="egom2p_base_12e_12d_swiglu_nobias", batch=1, n_enc=2048, n_dec=2048, budgets=None,
                 seed=5, full_float=False, py_seed=15),
 }
+
+
+def init_stats(out_dir, enc, dec, model):
+    """Per-parameter statistics of the reference's OWN constructor init (`init_weights`, egom2p_model.py:185-222, after
+    the embedding modules' `init`): mean, std, min, max of every parameter of the tied and the untied 2+2-layer ego-b.
+    They pin the distributions `Engine.init_random` / `EgoM2P.init_weights` must draw from."""
+    gold = {}
+    for tag, cfg_name in (("tied", "ego_b_2e_2d"), ("untied", "ego_b_2e_2d_untied")):
+        torch.manual_seed(1234)
+        net = build_reference_model(MODEL_CFGS[cfg_name], enc, dec, model)
+        names, rows = [], []
+        for n, p in net.state_dict().items():
+            if n.endswith("pos_emb") or (n.endswith(".bias") and "norm" in n):
+                continue
+            v = p.detach().double()
+            names.append(n)
+            rows.append([v.mean().item(), v.std().item() if v.numel() > 1 else 0.0, v.min().item(), v.max().item(), float(v.numel())])
+        gold[f"{tag}.names"] = np.array(names)
+        gold[f"{tag}.stats"] = np.array(rows, dtype=np.float64)
+    gold["meta"] = np.array(repr(dict(what="reference init_weights statistics", seed=1234)))
+    path = os.path.join(out_dir, "init_stats.npz")
+    np.savez_compressed(path, **gold)
+    print(f"[goldens] init_stats -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
 
 
 def main():
@@ -271,6 +299,8 @@ def main():
     args = ap.parse_args()
     enc, dec, model = load_reference()
     torch.set_num_threads(8)
+    if not args.only or "init_stats" in args.only.split(","):
+        init_stats(args.out, enc, dec, model)
     for case, kw in CASES.items():
         if args.only and case not in args.only.split(","):
             continue

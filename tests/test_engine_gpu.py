@@ -43,7 +43,7 @@ def _tap(g, key, t):
     return max(e1, e2, e3)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "b2", "b2_ragged", "b12", "L2"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "b2", "b2_ragged", "b2_untied", "b12", "L2"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim
@@ -108,10 +108,14 @@ def test_engine_matches_reference(case):
     for n, ref_sq in zip(names, sq):
         gr = eng.grad_of(n)
         got_sq = gr.double().pow(2).sum().item()
+        if ref_sq < 0:          # the reference left .grad None (untied decoder token table: its rows are never read, :328)
+            assert got_sq == 0.0, n
+            continue
         err = abs(got_sq ** 0.5 - ref_sq ** 0.5) / max(ref_sq ** 0.5, 1e-12)
         if err > worst[1]:
             worst = (n, err)
     assert worst[1] < GRAD_TOL, worst
+    # (tied tensors appear under both of their names in the reference's named_parameters() only once: names are unique)
     total = sum(eng.grad_of(n).double().pow(2).sum().item() for n in names) ** 0.5
     assert abs(total - float(g["grad_total_norm"])) < 1e-2 * float(g["grad_total_norm"])
     coef = min(1.0, 1.0 / (float(g["clip_total_norm"]) + 1e-6))

@@ -103,3 +103,92 @@ def test_registry_and_scope_errors():
         logits = model({k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}, 256, 256, return_logits=True)
     assert logits["tok_rgb"].shape == (1, 256, 64000) and logits["tok_cam"].shape == (1, 256, 256)
     assert torch.isfinite(logits["tok_rgb"].float()).all()
+
+
+def _ego_b_2e_2d_model():
+    mods = ["tok_rgb", "tok_depth", "tok_cam", "tok_gaze"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    return EgoM2P(enc, dec, {m: MODALITY_INFO[m] for m in mods}, dim=768, encoder_depth=2, decoder_depth=2, num_heads=12,
+                  mlp_ratio=4, qkv_bias=False, proj_bias=False, mlp_bias=False,
+                  norm_layer=partial(LayerNorm, eps=1e-6, bias=False), act_layer=nn.SiLU, gated_mlp=True)
+
+
+def _check_init(named_tensors, g, tag):
+    """every parameter against the statistics of the reference's own constructor init (tests/golden/init_stats.npz,
+    made by oracle/make_goldens.py:init_stats from egom2p_model.py:185-222): same family, same scale."""
+    for n, (mean, std, mn, mx, numel) in zip([str(x) for x in g[f"{tag}.names"]], g[f"{tag}.stats"]):
+        t = named_tensors[n].double().flatten()
+        assert t.numel() == int(numel), n
+        if std == 0.0:                                          # LayerNorm weight 1, Linear bias 0
+            assert float((t - mean).abs().max()) == 0.0, n
+            continue
+        bound = max(abs(mn), abs(mx))
+        s, amax = float(t.std()), float(t.abs().max())
+        rel = 4.0 / np.sqrt(2.0 * numel) + 2e-3                 # 4 sigma of a std estimate from numel samples
+        assert abs(s - std) < rel * std, (n, s, std)
+        assert abs(float(t.mean()) - mean) < 6.0 * std / np.sqrt(numel) + 1e-7, (n, float(t.mean()), mean)
+        if bound / std < 1.8:                                   # uniform(-a, a): a / std = sqrt(3); normal: >= 3
+            assert amax <= bound * (1 + 1e-3) and amax >= bound * (1 - 1e-2), (n, amax, bound)
+        else:
+            assert amax / s > 2.5, (n, amax / s)
+
+
+def test_init_weights_match_reference_distributions():
+    """SURVEY section 8 row a14 / ADVICE r1: xavier-uniform linears with qkv / kv as 3 / 2 matrices, N(0, 0.02) encoder
+    tables / mod_emb / mask_token, and the tied decoder table xavier-uniform on [V, D] (the `to_logits` Linear is
+    initialised after the Embedding it shares its weight with)."""
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN_DIR, "init_stats.npz"), allow_pickle=False)
+    torch.manual_seed(5)
+    model = _ego_b_2e_2d_model()
+    _check_init(model.state_dict(), g, "tied")
+    # the engine's own device-side initialiser (bench.py / run_training_egom2p.py --init random), tied and untied
+    from egom2p_amd.engine import Engine
+    for tag, cfg_name in (("tied", "ego_b_2e_2d"), ("untied", "ego_b_2e_2d_untied")):
+        eng = Engine(MODEL_CFGS[cfg_name], "cuda:0", max_batch=1, n_enc=64, n_dec=64)
+        eng.init_random(seed=3)
+        _check_init(eng.state_dict(), g, tag)
+        del eng
+
+
+def test_frozen_encoder_steps_match_torch_adamw_on_the_unfrozen_subset():
+    """with frozen tensors (`freeze_encoder`) the clip norm covers only tensors that have a gradient, the
+    frozen tensors stay untouched, and nothing accumulates in the flat gradient buffer from step to step."""
+    g, meta = load_golden("tiny")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    model = _tiny_model()
+    model.load_state_dict(sd)
+    model.freeze_encoder()
+    args = types.SimpleNamespace(opt="adamw", lr=1e-2, weight_decay=0.05, opt_betas=(0.9, 0.95), opt_eps=1e-8)
+    opt = create_optimizer(args, model)
+    scaler = NativeScalerWithGradNormCount(enabled=False)
+    named = dict(model.named_parameters())
+    live = [n for n, p in named.items() if p.requires_grad]
+    frozen = [n for n, p in named.items() if not p.requires_grad]
+    assert frozen and live
+    frozen0 = {n: named[n].detach().clone() for n in frozen}
+    # torch reference on clones of the unfrozen tensors, fed with the engine's own gradients
+    ref = {n: named[n].detach().clone().requires_grad_(True) for n in live}
+    nd = lambda n: ("norm." in n or ".norm" in n or n.endswith(".bias"))
+    topt = torch.optim.AdamW([{"params": [ref[n] for n in live if not nd(n)], "weight_decay": 0.05},
+                              {"params": [ref[n] for n in live if nd(n)], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    clip = 0.05                                                   # below the gradient norm: the clip coefficient matters
+    for step in range(3):
+        random.seed(meta["py_seed"] + step)
+        loss, _ = model(mdg, meta["n_enc"], meta["n_dec"])
+        loss.backward()
+        for n in live:
+            ref[n].grad = named[n].grad.detach().clone()
+        tnorm = torch.nn.utils.clip_grad_norm_([ref[n] for n in live], clip)
+        topt.step()
+        norm = opt.step(clip_grad=clip)
+        assert tnorm.item() > clip
+        assert abs(norm.item() - tnorm.item()) < 1e-5 * tnorm.item(), (step, norm.item(), tnorm.item())
+        for n in live:
+            assert rel_l2(named[n].detach().float().cpu().numpy(), ref[n].detach().float().cpu().numpy()) < 2e-6, (step, n)
+        for n in frozen:
+            assert torch.equal(named[n].detach(), frozen0[n]), n
+        assert float(model.engine.G.abs().max().item()) == 0.0    # frozen ranges are cleared too

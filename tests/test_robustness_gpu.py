@@ -1,0 +1,128 @@
+"""Boundary / robustness behaviour on the GPU: the compaction error flag reaches the loss, the
+overlapped gradient-bucket reducer is bit-transparent on a one-rank RCCL group, state-dict loading tolerates foreign keys,
+the captured-graph cache is bounded and dropped when memory is re-allocated."""
+import os
+import random
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from egom2p_amd import synth  # noqa: E402
+from egom2p_amd.config import MODEL_CFGS  # noqa: E402
+from egom2p_amd.dp import GradBucketReducer  # noqa: E402
+from egom2p_amd.engine import Engine  # noqa: E402
+from egom2p_amd.model import MODALITY_INFO, EgoM2P, LayerNorm  # noqa: E402
+
+
+def _tiny_pad():
+    g, meta = load_golden("tiny_pad")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"])
+    eng.load_state_dict(sd)
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    return g, meta, cfg, eng, mdg
+
+
+def test_non_interval_decoder_mask_poisons_the_loss():
+    """A decoder_attention_mask whose running sum reaches past the valid targets would let padding keys be attended:
+    adapt_decoder_attention_mask (egom2p_model.py:446-481) then is not one key interval per row.  The compaction kernel
+    flags it and the loss comes out NaN (the reference loop stops on a non-finite loss, run_training_egom2p.py:731-734);
+    the next, well-formed step is unaffected."""
+    g, meta, cfg, eng, md = _tiny_pad()
+    order = [str(x) for x in g["dec_order"]]
+    good, _ = eng.forward(md, dec_order=order)
+    good = float(good)
+    assert np.isfinite(good)
+    bad = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in md.items()}
+    bad["tok_cam"]["decoder_attention_mask"] = bad["tok_cam"]["decoder_attention_mask"] + 7     # sums exceed the target count
+    loss, mod_loss = eng.forward(bad, dec_order=order)
+    assert torch.isnan(loss) and all(torch.isnan(v) for v in mod_loss.values())
+    again, _ = eng.forward(md, dec_order=order)                                              # flag was consumed
+    assert float(again) == good
+    with pytest.raises(Exception):
+        eng.forward_logits(bad, dec_order=order)
+    assert int(eng.cd["err"].item()) == 0
+
+
+def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
+    """the event on the compute stream, the all_reduce on the comm stream and finish() had never run on a GPU.
+    World size 1 makes the all-reduce the identity, so gradients must be bitwise those of the plain path, and the buckets
+    must tile [0, n_flat) exactly once."""
+    import torch.distributed as dist
+    g, meta, cfg, eng, md = _tiny_pad()
+    order = [str(x) for x in g["dec_order"]]
+    eng.zero_grad()
+    eng.forward(md, dec_order=order)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    plain = eng.G.clone()
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        red = GradBucketReducer(eng.G, None, bucket_cap_mb=0.25, force=True)
+        assert red.active
+        for rep in range(2):
+            eng.zero_grad()
+            eng.forward(md, dec_order=order)
+            eng.backward(1.0, bucket_done=red.on_bucket)
+            red.finish()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.G, plain)
+            spans = sorted(red.last_launched)
+            assert spans[0][0] == 0 and spans[-1][1] == eng.n_flat
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])), spans
+            assert len(spans) > 1
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
+def test_load_state_dict_reports_foreign_keys():
+    mods = ["tok_cam", "tok_gaze"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    model = EgoM2P(enc, dec, {m: MODALITY_INFO[m] for m in mods}, dim=128, encoder_depth=2, decoder_depth=2, num_heads=2,
+                   mlp_ratio=4, qkv_bias=False, proj_bias=False, mlp_bias=False,
+                   norm_layer=partial(LayerNorm, eps=1e-6, bias=False), act_layer=nn.SiLU, gated_mlp=True)
+    sd = synth.build_state_dict(MODEL_CFGS["ego_tiny_2e_2d"], 3)
+    sd["encoder_embeddings.tok_rgb.token_emb.weight"] = torch.zeros(4, 128)       # a checkpoint with an extra modality
+    sd["optimizer_extra"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(sd, strict=True)
+    res = model.load_state_dict(sd, strict=False)
+    assert set(res.unexpected_keys) == {"encoder_embeddings.tok_rgb.token_emb.weight", "optimizer_extra"} and not res.missing_keys
+    assert torch.equal(model.state_dict()["mask_token"].cpu(), sd["mask_token"])
+
+
+def test_graph_cache_is_bounded_and_dropped_on_reallocation():
+    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=64, n_dec=64)
+    eng.init_random(4)
+    eng.max_graphs = 2
+    ids = synth.randint("lru.rgb", (1, 5120), 64000, seed=1).cuda()
+    mask = torch.zeros(1, 5120, dtype=torch.bool, device="cuda")
+    mask[:, 3000:] = True
+    enc = {"tok_rgb": (ids, mask)}
+    pos = torch.arange(200, device="cuda")[None]
+    outs = {}
+    for n_enc in (1000, 2000, 3000, 1000):                 # three shapes through a cache of two; the first one is re-captured
+        out = eng.infer_logits_graphed(enc, n_enc, "tok_depth", pos)
+        ref = eng.infer_logits(enc, n_enc, "tok_depth", pos)
+        assert torch.equal(out, ref)
+        assert len(eng._graphs) <= 2
+        outs[n_enc] = out.clone()
+    eng.resize_workspaces(2, 64, 64)
+    assert "_graphs" not in eng.__dict__
+    out = eng.infer_logits_graphed(enc, 1000, "tok_depth", pos)
+    assert torch.equal(out, outs[1000])

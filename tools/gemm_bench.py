@@ -42,7 +42,7 @@ def main():
             P = (torch.rand(M, Ni, device=dev) * 2 - 1).bfloat16()
             Q = (torch.rand(M, Nj, device=dev) * 2 - 1).bfloat16()
             C = torch.zeros(Ni, Nj, device=dev)
-            splits = ops.tn_splits(Ni, Nj, M, slab.numel(), wgs256=int(os.environ.get('TN_WGS256', '256')))
+            splits = ops.tn_splits(Ni, Nj, M, slab.numel())
             t = timeit(lambda: ops.gemm_tn(P, Q, C, Ni, Nj, M, splits=splits, slab=slab if splits > 1 else None))
             res[f"tn {M}x{Ni}x{Nj} s{splits}"] = round(2.0 * M * Ni * Nj / t / 1e12, 1)
             del P, Q, C

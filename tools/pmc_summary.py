@@ -9,8 +9,12 @@ as 64 B, so it is doubled (MI355X_MICROARCH.md, section HBM).  WRITE_SIZE is exa
 import csv
 import json
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egom2p_amd.profiler import kernel_source_sha  # noqa: E402
 
 CLASSES = [("gemm_nt256", r"gemm_nt256_kernel"), ("gemm_nt", r"gemm_nt_kernel"), ("gemm_tn256", r"gemm_tn256_kernel"),
            ("gemm_tn", r"gemm_tn_kernel"), ("attn_fwd", r"attn_fwd_kernel"), ("attn_bwd_dq", r"attn_bwd_dq_kernel"),
@@ -55,7 +59,7 @@ def main():
                     "per the gfx950 correction (MI355X_MICROARCH.md, HBM); counter units KiB -> bytes",
             "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --clips-per-gpu 32 --steps 1 "
                        "--warmup 0 --no-cpu-baseline --no-kernel-profile",
-            "micro_batch": 32, "kernels": out, "abi": abi}
+            "micro_batch": 32, "kernel_src_sha": kernel_source_sha(), "kernels": out, "abi": abi}
     json.dump(meta, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
