@@ -52,9 +52,9 @@ _SIGS = {
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "ego_gemm_tn_plan": [i32, i32, i32, i64, i64, i64, i32],
-    "ego_attn_fwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64,
+    "ego_attn_fwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64,
                          i32, i32, i32, i32, f32, vp],
-    "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp,
+    "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
                          vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
     "ego_clip_synth": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_swiglu_fwd": [vp, vp, i64, i32, vp],

@@ -31,14 +31,15 @@ struct AttnArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V;
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;
     bf16_t* O; long o_bs, o_rs;
-    float* LSE;                 // [B,H,Nq] log2-domain log-sum-exp of the scaled scores
+    bf16_t* Olo;                // optional, laid out like O: bf16(o - bf16(o)), the rounding residual of the stored output
+    float* LSE;                 // [B,H,Nq] MINUS the log2-domain log-sum-exp of the scaled scores (the backward's accumulator init)
     const int* ks; const int* ke;  // interval of query row (b,q) at [b*r_bs + q*r_rs]
     long r_bs, r_rs;
     int B, H, Nq, Nk;
     float scale;
     // backward only
     const bf16_t* dO; long do_bs, do_rs;
-    const float* DELTA;         // [B,H,Nq]  (read by the dK/dV kernel)
+    const float* DELTA;         // [B,H,Nq]  MINUS rowsum(dO o O) (read by the dK/dV kernel)
     float* DELTA_OUT;           // same buffer, written by the dQ kernel
     bf16_t* dQ; long dq_bs, dq_rs;
     bf16_t* dK; long dk_bs, dk_rs;
@@ -165,6 +166,23 @@ __device__ __forceinline__ void dma_tile64(__amdgpu_buffer_rsrc_t rsrc, long rs,
     for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (2 * wave + i) * 1024), 16,
                                                  off.o[i], soff, 0, 0);
+}
+
+// the same rows as two bf16 numbers per element: hi = bf16(x), lo = bf16(x - hi) (x to ~16 significant bits)
+__device__ __forceinline__ void store_rows_bf16_hilo(bf16_t* hi, bf16_t* lo, const f32x16 (&t)[2], float mul, int hh) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + 8 * g + 4 * hh;
+            float x[4], r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = t[db][4 * g + e] * mul; r[e] = x[e] - round_bf16(x[e]); }
+            u32x2 o = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+            u32x2 q = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+            *(u32x2*)(hi + d0) = o;
+            *(u32x2*)(lo + d0) = q;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -320,15 +338,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     if (q0 + ql < p.Nq) {
-        store_rows_bf16(p.O + (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64, ot, inv, hh);
-        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = m * sc + __builtin_amdgcn_logf(lt);  // v_log_f32 = log2
+        const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
+        if (p.Olo) store_rows_bf16_hilo(p.O + oo, p.Olo + oo, ot, inv, hh);
+        else store_rows_bf16(p.O + oo, ot, inv, hh);
+        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = -(m * sc + __builtin_amdgcn_logf(lt));  // v_log_f32 = log2; stored NEGATED
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, query-major: dQ
+// backward, query-major: dQ (also forms delta = rowsum(dO o O) and stores -delta for the dK / dV kernel, which runs behind
+// this one on the stream).  Two waves per SIMD: Q is pre-scaled by scale * log2(e) and the row constants -LSE2 / -delta
+// sit in two 16-register blocks that serve as the INITIAL accumulators of every S' / dP' chain, so the element-wise part
+// is p = exp2(S'), dS' = p * dP' (the factor `scale` goes into the final dQ store); both 32-key halves of a tile have
+// their S' / dP' chains issued before the element-wise work of the first one starts.  (The three-waves-per-SIMD form
+// with fma(S, sc, -LSE2) / fma(dP, scale, -delta * scale) per element ran 4-7 % slower: these kernels are bound by
+// vector-instruction issue, not by occupancy.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
 
     int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
     float sc = p.scale * LOG2E, gsc = p.scale;
-    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
+    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }       // empty interval: q' = 0 -> p = exp2(-LSE2) = 1 / Nk, dQ = 0
     const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
     const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
     int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
@@ -353,27 +379,35 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
     const bf16_t* Gp = p.dO + (long)b * p.do_bs + (long)qrow * p.do_rs + h * 64;
     bf16x8 qf[4], gf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
-        gf[s] = *(const bf16x8*)(Gp + 16 * s + 8 * hh);
-    }
-    const float lse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];
-    // delta[b,h,q] = sum_d dO * O of this wave's rows: formed here from the dO fragments already in registers (each
-    // half-wave holds 32 of the 64 dims) and stored for the dK/dV kernel, which runs behind this one on the stream
     float delta = 0.f;
     {
         const bf16_t* Op = p.O + (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            const bf16x8 qr = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+            gf[s] = *(const bf16x8*)(Gp + 16 * s + 8 * hh);
             const bf16x8 of = *(const bf16x8*)(Op + 16 * s + 8 * hh);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) delta += (float)of[e] * (float)gf[s][e];
+            for (int e = 0; e < 8; ++e) {
+                qf[s][e] = (__bf16)((float)qr[e] * sc);
+                delta += (float)of[e] * (float)gf[s][e];
+            }
+            // delta multiplies EVERY key's dS: the 2^-9 rounding of the stored O shows up in dQ as (delta error) x
+            // (attention-weighted mean of K), against a true dQ that only sees K's deviations from that mean.  With the
+            // rounding residual of O (written by the forward) delta is good to ~2^-17.
+            if (p.Olo) {
+                const bf16x8 ol = *(const bf16x8*)(p.Olo + (Op - p.O) + 16 * s + 8 * hh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) delta += (float)ol[e] * (float)gf[s][e];
+            }
         }
         delta += __shfl_xor(delta, 32, 64);
-        if (hh == 0 && q0 + ql < p.Nq) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = delta;
+        if (hh == 0 && q0 + ql < p.Nq) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = -delta;
     }
-    const float dgs = delta * gsc;
+    const float nlse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];       // -LSE2
+    f32x16 c_lse, c_del;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c_lse[i] = nlse2; c_del[i] = -delta; }
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
@@ -387,10 +421,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
     f32x16 dqt[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
-
     const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
-    // K / V ring of FWD_STAGES tiles, filled two tiles ahead (see attn_fwd_kernel); the Q / dO fragments and row scalars
-    // fetched at kernel entry are waited for here, not at their first use inside the loop
     if (kt0 < kt1) dma_tile(kt0, 0);
     if (kt0 + 1 < kt1) {
         dma_tile(kt0 + 1, 1);
@@ -407,42 +438,36 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
         if (ahead) dma_tile(kt + 2, s_ >= 1 ? s_ - 1 : 2);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
-        // dS^T = P o (dP^T - delta) * scale.  Interior tiles (every row of the wave sees all 64 keys) skip the
-        // interval compares: at head_dim 64 these kernels are VALU-bound, not MFMA-bound.  The two 32-key halves
-        // are processed one after the other so that only one S / dP accumulator pair is live (3 waves per SIMD).
         const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        f32x16 st[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 st, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+            st[kb] = c_lse; dp[kb] = c_del;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp, 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, kb, s, lane), gf[s], dp[kb], 0, 0, 0);
             }
-            // K^T fragments of this 32-key half (dQ operands): asm transposed reads, in flight under the arithmetic
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
             s16x4 kfr[4][2];
             if (kb == 0) tr_issue<0, 0>(tra, s_ * 2 * TILE_BYTES, kfr); else tr_issue<0, 2>(tra, s_ * 2 * TILE_BYTES, kfr);
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -lse2));
-                    st[r] = pv * __builtin_fmaf(dp[r], gsc, -dgs);
-                }
+                for (int r = 0; r < 16; ++r) st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r]) * dp[kb][r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
                     const bool ok = (kidx >= ks && kidx < ke);
-                    const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -lse2)) : 0.f;
-                    st[r] = pv * __builtin_fmaf(dp[r], gsc, -dgs);
+                    st[kb][r] = ok ? __builtin_amdgcn_exp2f(st[kb][r]) * dp[kb][r] : 0.f;
                 }
             }
             lgkm_wait_tied<0>(kfr);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                const bf16x8 dsf = pack8(st, x);
+                const bf16x8 dsf = pack8(st[kb], x);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
                     dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(kfr[2 * x + db][0], kfr[2 * x + db][1]), dsf, dqt[db], 0, 0, 0);
@@ -454,17 +479,74 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs p) {
         s_ = (s_ == 2) ? 0 : s_ + 1;
     }
     if (q0 + ql < p.Nq)
-        store_rows_bf16(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * 64, dqt, 1.f, hh);
+        store_rows_bf16(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * 64, dqt, gsc, hh);
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward, key-major: dK, dV
+//
+// One workgroup = 4 waves = 128 keys of one (batch, head); a wave keeps dK^T and dV^T of its 32 keys in 64 accumulator
+// registers and sweeps the q tiles (64 rows = two 32-row blocks) that can see them.  Per block: S' = Q.K'^T - LSE2 and
+// dP' = dO.V^T - delta leave their MFMA chains ready-made (K' = K * scale * log2 e in the wave's registers; the row
+// constants -LSE2 / -delta are the chains' INITIAL accumulators, read from LDS in the accumulator's row order), so the
+// element-wise work is p = exp2(S') and dS' = p * dP': two VALU instructions per score (the factor `scale` of dS is
+// applied once, when dK is stored).
+//
+// Every LDS read of the loop is issued by hand (inline asm, counted waits): the fragments and row constants of a block
+// are fetched while the PREVIOUS block's dV / dK MFMAs run, so a block's first MFMA never waits on an LDS round trip
+// (compiler-placed reads were issued two at a time right in front of their MFMA: the S / dP chain ran at LDS latency).
+// To make that prefetch legal across q tiles the "next tile has landed" barrier sits in the MIDDLE of an iteration:
+//     block 0 of tile t | wait DMA(t+1), barrier, issue DMA(t+R-1) | block 1 of tile t (prefetching block 0 of t+1)
+// R = DKV_STAGES ring slots of {Q tile, dO tile, 64 x {-LSE2, -delta, ks, ke}}; a tile is 5 LDS-DMA pieces per wave
+// (2 Q + 2 dO + one of the four row-constant arrays), so "at most 5 outstanding" = the next tile has landed.
 // ---------------------------------------------------------------------------------------------
-constexpr int DKV_STAGES = 3;                     // Q / dO ring, filled two q tiles ahead
-constexpr int AUX_OFF = DKV_STAGES * 2 * TILE_BYTES;   // per stage: lse2[64] delta[64] ks[64] ke[64] = 1 KiB
-constexpr int AGG_OFF = AUX_OFF + DKV_STAGES * 1024;   // per q tile {min ks, max ks, min ke, max ke}
+constexpr int DKV_STAGES = 4;
+constexpr int AUX_OFF = DKV_STAGES * 2 * TILE_BYTES;   // per stage: nlse2[64] ndelta[64] ks[64] ke[64] = 1 KiB
+constexpr int AGG_OFF = AUX_OFF + DKV_STAGES * 1024;   // per q tile {min ks, max ks, min ke, max ke} (per-row masks only)
 constexpr int DKV_MAX_QTILES = 512;
 constexpr int DKV_LDS = AGG_OFF + DKV_MAX_QTILES * 16;
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_rd128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_rd128f(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+// Per 32-row q block 16 LDS reads feed the S' / dP' chains: the Q / dO row fragments of the four k-steps and the
+// -LSE2 / -delta row constants (accumulator order: registers 4g..4g+3 = rows 8g + 4hh ..+3).  A wave issues in order and
+// an MFMA group holds it for 32 cycles per MFMA, so a read is only hidden by MFMAs issued AFTER it: all 16 go out in
+// front of the PREVIOUS block's dV / dK group.
+struct DkvBlk { bf16x8 rq[4], rg[4]; f32x4 cs[4], cd[4]; };
+
+template <int QB>
+__device__ __forceinline__ void dkv_issue(DkvBlk& k, const unsigned (&rfa)[4], unsigned auxa) {
+    k.cs[0] = lds_rd128f<QB * 128>(auxa);      k.cs[1] = lds_rd128f<QB * 128 + 32>(auxa);
+    k.cs[2] = lds_rd128f<QB * 128 + 64>(auxa); k.cs[3] = lds_rd128f<QB * 128 + 96>(auxa);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) k.rq[s] = lds_rd128<QB * 4096>(rfa[s]);
+    k.cd[0] = lds_rd128f<256 + QB * 128>(auxa);      k.cd[1] = lds_rd128f<256 + QB * 128 + 32>(auxa);
+    k.cd[2] = lds_rd128f<256 + QB * 128 + 64>(auxa); k.cd[3] = lds_rd128f<256 + QB * 128 + 96>(auxa);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) k.rg[s] = lds_rd128<TILE_BYTES + QB * 4096>(rfa[s]);
+}
+__device__ __forceinline__ void dkv_wait(DkvBlk& k) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(k.rq[0]), "+v"(k.rq[1]), "+v"(k.rq[2]), "+v"(k.rq[3]), "+v"(k.rg[0]), "+v"(k.rg[1]), "+v"(k.rg[2]), "+v"(k.rg[3]),
+                   "+v"(k.cs[0]), "+v"(k.cs[1]), "+v"(k.cs[2]), "+v"(k.cs[3]), "+v"(k.cd[0]), "+v"(k.cd[1]), "+v"(k.cd[2]), "+v"(k.cd[3])
+                 :: "memory");
+}
+__device__ __forceinline__ f32x16 cat16(const f32x4 (&c)[4]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    const f32x8 lo = __builtin_shufflevector(c[0], c[1], 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c[2], c[3], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
@@ -479,78 +561,82 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 
     const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)krow * p.k_rs + h * 64;
     const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)krow * p.v_rs + h * 64;
+    // K pre-scaled by scale * log2(e) (one more bf16 rounding of an operand that already is bf16)
+    const float c_sc = p.scale * LOG2E;
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = *(const bf16x8*)(Kp + 16 * s + 8 * hh);
+        const bf16x8 kr = *(const bf16x8*)(Kp + 16 * s + 8 * hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kf[s][e] = (__bf16)((float)kr[e] * c_sc);
         vf[s] = *(const bf16x8*)(Vp + 16 * s + 8 * hh);
     }
 
     const bf16_t* Qb = p.Q + (long)b * p.q_bs + h * 64;
     const bf16_t* Gb = p.dO + (long)b * p.do_bs + h * 64;
-    const float* LSEb = p.LSE + ((long)b * p.H + h) * p.Nq;
-    const float* DELb = p.DELTA + ((long)b * p.H + h) * p.Nq;
     const int* KSb = p.ks + b * p.r_bs;
     const int* KEb = p.ke + b * p.r_bs;
+    const bool per_row = p.r_rs != 0;
 
-    // Q / dO tiles arrive by LDS-DMA (dma_tile64); the four per-row scalars are staged through registers of wave 0:
-    // load_tile only issues the raw loads (first, so that the wait for them leaves the younger DMA in flight), store_aux
-    // derives the stored values at the end of the iteration - nothing in between depends on the loads
-    float r_lse = 0.f, r_del = 0.f;
-    int r_ks = 0, r_ke = 0, r_row = 0;
+    // tiles arrive by LDS-DMA: Q / dO through dma_tile64, and wave w copies row-constant array w of the tile's 64 rows
+    // (4 bytes per lane; rows past Nq read as zeros through the descriptor bounds)
     const DmaOff qoff = dma_off(p.q_rs, wave, lane), goff = dma_off(p.do_rs, wave, lane);
     const __amdgpu_buffer_rsrc_t qrs = slice_rsrc(Qb, p.q_rs, p.Nq), grs = slice_rsrc(Gb, p.do_rs, p.Nq);
+    const void* abase = wave == 0 ? (const void*)(p.LSE + ((long)b * p.H + h) * p.Nq)
+                      : wave == 1 ? (const void*)(p.DELTA + ((long)b * p.H + h) * p.Nq)
+                      : wave == 2 ? (const void*)KSb : (const void*)KEb;
+    const bool a_row = wave < 2 || per_row;                         // array indexed by the q row (else one value per sample)
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, a_row ? p.Nq * 4 : 4, 0x00020000);
+    const unsigned aoff = a_row ? lane * 4 : 0;
     auto load_tile = [&](int qt, int s) {
-        if (tid < 64) {
-            r_row = qt * 64 + tid;
-            const int row = min(r_row, p.Nq - 1);
-            r_lse = LSEb[row]; r_del = DELb[row];
-            r_ks = KSb[row * p.r_rs]; r_ke = KEb[row * p.r_rs];
-        }
         dma_tile64(qrs, p.q_rs, qoff, qt * 64, smem + s * 2 * TILE_BYTES, wave);
         dma_tile64(grs, p.do_rs, goff, qt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
-    };
-    auto store_aux = [&](int s) {
-        if (tid < 64) {
-            float a_lse = 0.f, a_del = 0.f;
-            int a_ks = INT_MAX, a_ke = 0;                     // rows past Nq (the DMA zero-fills them): never attended
-            if (r_row < p.Nq) {
-                a_lse = r_lse; a_del = r_del * p.scale;       // delta * scale: dS = P * fma(dP, scale, -delta*scale)
-                a_ks = r_ks; a_ke = min(r_ke, p.Nk);
-                if (a_ke <= a_ks) { a_ks = -1; a_ke = p.Nk; }   // empty interval: uniform attention, zero score scale
-            }
-            float* af = (float*)(smem + AUX_OFF + s * 1024);
-            int* ai = (int*)(smem + AUX_OFF + s * 1024 + 512);
-            af[tid] = a_lse; af[64 + tid] = a_del; ai[tid] = a_ks; ai[64 + tid] = a_ke;
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + AUX_OFF + s * 1024 + wave * 256), 4,
+                                                 aoff, a_row ? qt * 256 : 0, 0, 0);
     };
 
     f32x16 dkt[2], dvt[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
-    const float c_sc = p.scale * LOG2E;
-    const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const TrAddr tra = tr_addr(lds0, lane);
+    // row-fragment addresses (stage 0, block 0, Q tile): row lane & 31, 16-byte chunk (2s + hh) ^ swizzle(row)
+    unsigned rfb[4];
+    {
+        const int r = lane & 31, v = (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rfb[s] = lds0 + r * 128 + (((2 * s + hh) ^ v) << 4);
+    }
+    const unsigned auxb = lds0 + AUX_OFF + 16 * hh;
 
-    // One pass over the intervals of this batch row: per 64-row q tile the four extremes {min ks, max ks, min ke,
-    // max ke} go to LDS (flat rows count as ks = -1 / ke = Nk, rows past Nq as ks = INT_MAX / ke = 0, like the per-row
-    // copies below).  They give (a) the range of q tiles that can touch this workgroup's 128 keys - block-diagonal
-    // decoder masks and padded encoder keys leave most (q tile, key block) pairs empty - and (b) the per-tile
-    // "skip" / "every row sees all my keys" decisions of each wave as scalar compares (no wave reductions per tile).
+    // Range of q tiles that can touch this workgroup's 128 keys, and (per-row masks) per-tile interval summaries.
+    int qt0, nqt;
     int* agg = (int*)(smem + AGG_OFF);
     const int nq_tiles = (p.Nq + 63) >> 6;
-    for (int base = wave * 64; base < nq_tiles * 64; base += 256) {
-        const int r = base + lane;
-        int a = INT_MAX, e = 0;
-        if (r < p.Nq) {
-            a = KSb[r * p.r_rs]; e = min(KEb[r * p.r_rs], p.Nk);
-            if (e <= a) { a = -1; e = p.Nk; }
+    int u_ks = 0, u_ke = 0;                 // the sample's interval when it is uniform
+    if (!per_row) {
+        u_ks = KSb[0]; u_ke = min(KEb[0], p.Nk);
+        if (u_ke <= u_ks) { u_ks = -1; u_ke = p.Nk; }               // empty interval: uniform attention, zero score scale
+        const bool touch = max(u_ks, 0) < tile * 128 + 128 && u_ke > tile * 128;
+        qt0 = 0; nqt = touch ? nq_tiles : 0;
+    } else {
+        // One pass over the intervals of this batch row: per 64-row q tile the four extremes {min ks, max ks, min ke,
+        // max ke} go to LDS (flat rows count as ks = -1 / ke = Nk, rows past Nq as ks = INT_MAX / ke = 0).  They give (a)
+        // the range of q tiles that can touch this workgroup's 128 keys - block-diagonal decoder masks and padded encoder
+        // keys leave most (q tile, key block) pairs empty - and (b) the per-tile "skip" / "every row sees all my keys"
+        // decisions of each wave as scalar compares (no wave reductions per tile).
+        for (int base = wave * 64; base < nq_tiles * 64; base += 256) {
+            const int r = base + lane;
+            int a = INT_MAX, e = 0;
+            if (r < p.Nq) {
+                a = KSb[r * p.r_rs]; e = min(KEb[r * p.r_rs], p.Nk);
+                if (e <= a) { a = -1; e = p.Nk; }
+            }
+            const int a_min = wave_min_i(a), a_max = wave_max_i(a), e_min = wave_min_i(e), e_max = wave_max_i(e);
+            if (lane == 0) { int* g4 = agg + 4 * (base >> 6); g4[0] = a_min; g4[1] = a_max; g4[2] = e_min; g4[3] = e_max; }
         }
-        const int a_min = wave_min_i(a), a_max = wave_max_i(a), e_min = wave_min_i(e), e_max = wave_max_i(e);
-        if (lane == 0) { int* g4 = agg + 4 * (base >> 6); g4[0] = a_min; g4[1] = a_max; g4[2] = e_min; g4[3] = e_max; }
-    }
-    __syncthreads();
-    int q_first = INT_MAX, q_last = -1;
-    {
+        __syncthreads();
+        int q_first = INT_MAX, q_last = -1;
         const int kb0 = tile * 128, kb1 = kb0 + 128;
         for (int t = tid; t < nq_tiles; t += 256)
             if (max(agg[4 * t], 0) < kb1 && agg[4 * t + 3] > kb0) { q_first = min(q_first, t); q_last = max(q_last, t); }
@@ -561,126 +647,166 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         q_first = min(min(red[0], red[1]), min(red[2], red[3]));
         q_last = max(max(red[4], red[5]), max(red[6], red[7]));
         __syncthreads();
+        qt0 = (q_last < 0) ? 0 : q_first;
+        nqt = (q_last < 0) ? 0 : q_last + 1;
     }
-    const int qt0 = (q_last < 0) ? 0 : q_first;
-    const int nqt = (q_last < 0) ? 0 : q_last + 1;
-    // ring of DKV_STAGES q tiles, filled two tiles ahead; every tile is 4 DMA instructions of this wave, so "at most 4
-    // outstanding" means the older tile has landed
-    if (qt0 < nqt) {
-        load_tile(qt0, 0);
-        store_aux(0);
-    }
-    if (qt0 + 1 < nqt) {
-        load_tile(qt0 + 1, 1);
-        store_aux(1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ring prologue: tiles qt0 .. qt0 + R - 2 in flight, the first one landed
+    constexpr int R = DKV_STAGES;
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) if (qt0 + i < nqt) load_tile(qt0 + i, i);
+    {
+        const int stay = min(nqt - qt0, R - 1) - 1;                 // tiles issued, minus the first one (must land now)
+        if (stay >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (stay == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (stay == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
-    // The K / V fragments were fetched by plain global loads at kernel entry.  Their first use is inside the loop, and
-    // hipcc puts the s_waitcnt there: a vmcnt(0) executed in EVERY iteration, which also drains the LDS-DMA just issued
-    // for the tiles ahead (the whole prefetch serialised behind it).  Naming the registers here moves that wait in
-    // front of the loop.
+    // The K / V fragments were fetched by plain global loads at kernel entry: naming them here keeps hipcc's wait for
+    // them (a vmcnt(0), which would also drain the LDS-DMA of the tiles ahead) out of the loop.
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));
-    int s_ = 0;
-    for (int qt = qt0; qt < nqt; ++qt) {
-        const bool ahead = qt + 2 < nqt;
-        const int s2 = s_ >= 1 ? s_ - 1 : 2;               // stage of tile qt + 2: last read before the previous barrier
-        if (ahead) load_tile(qt + 2, s2);
-        const char* Qt = smem + s_ * 2 * TILE_BYTES;
-        const char* Gt = Qt + TILE_BYTES;
-        const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);
-        const int* ai = (const int*)(smem + AUX_OFF + s_ * 1024 + 512);
 
-        // does any row of this q tile look at this wave's 32 keys, and do all of them see all 32?  (scalar)
-        const int g_ksmin = __builtin_amdgcn_readfirstlane(agg[4 * qt]), g_ksmax = __builtin_amdgcn_readfirstlane(agg[4 * qt + 1]);
-        const int g_kemin = __builtin_amdgcn_readfirstlane(agg[4 * qt + 2]), hi = __builtin_amdgcn_readfirstlane(agg[4 * qt + 3]);
-        // (flat rows carry ks = -1, rows beyond Nq carry ks = INT_MAX: both force the general path)
-        const bool tile_full = g_ksmin >= 0 && g_ksmax <= kw0 && g_kemin >= kw0 + 32;
-        const int lo = max(g_ksmin, 0);
-        if (hi > kw0 && lo < kw0 + 32) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16 st, dp;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, qb, s, lane), kf[s], st, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gt, qb, s, lane), vf[s], dp, 0, 0, 0);
-                }
-                // dO / Q fragments for dV^T and dK^T (asm transposed reads): in flight under the exp / scale arithmetic
-                s16x4 gfr[4][2], qfr[4][2];
-                if (qb == 0) {
-                    tr_issue<TILE_BYTES, 0>(tra, s_ * 2 * TILE_BYTES, gfr);
-                    tr_issue<0, 0>(tra, s_ * 2 * TILE_BYTES, qfr);
-                } else {
-                    tr_issue<TILE_BYTES, 2>(tra, s_ * 2 * TILE_BYTES, gfr);
-                    tr_issue<0, 2>(tra, s_ * 2 * TILE_BYTES, qfr);
-                }
-                f32x16 pv, ds;
-                if (tile_full) {
-                    // every row of this q tile sees all 32 keys of this wave: no interval compares
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int qb0 = qb * 32 + 8 * g + 4 * hh;           // 4 consecutive q rows
-                        const f32x4 lse4 = *(const f32x4*)(af + qb0);
-                        const f32x4 del4 = *(const f32x4*)(af + 64 + qb0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * g + e;
-                            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c_sc, -lse4[e]));
-                            pv[r] = pe;
-                            ds[r] = pe * __builtin_fmaf(dp[r], p.scale, -del4[e]);
-                        }
-                    }
-                } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int qb0 = qb * 32 + 8 * g + 4 * hh;           // 4 consecutive q rows
-                    const f32x4 lse4 = *(const f32x4*)(af + qb0);
-                    const f32x4 del4 = *(const f32x4*)(af + 64 + qb0);
-                    typedef int i32x4 __attribute__((ext_vector_type(4)));
-                    const i32x4 ks4 = *(const i32x4*)(ai + qb0);
-                    const i32x4 ke4 = *(const i32x4*)(ai + 64 + qb0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const bool ok = (kidx >= ks4[e]) && (kidx < ke4[e]);
-                        const bool flat = ks4[e] < 0;
-                        const float x = flat ? 0.f : st[r] * c_sc;
-                        const float pe = ok ? __builtin_amdgcn_exp2f(x - lse4[e]) : 0.f;
-                        pv[r] = pe;
-                        ds[r] = flat ? 0.f : pe * __builtin_fmaf(dp[r], p.scale, -del4[e]);
-                    }
-                }
-                }
-                lgkm_wait_tied<0>(gfr);
-                lgkm_wait_tied<0>(qfr);
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    const bf16x8 pf = pack8(pv, x), dsf = pack8(ds, x);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 * x + db][0], gfr[2 * x + db][1]), pf, dvt[db], 0, 0, 0);
-                        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 * x + db][0], qfr[2 * x + db][1]), dsf, dkt[db], 0, 0, 0);
-                    }
-                }
+    // q tiles that can touch THIS wave's 32 keys: [wa, wb) inside [qt0, nqt).  Outside it the wave only keeps the ring
+    // going (its DMA pieces, the barriers); inside it every tile is computed (a tile in between that does not look at
+    // these keys comes out as all-zero P through the general path).  Keeping the "skip" decision out of the compute
+    // loop matters: with it inside, hipcc kept a second copy of the 64 dK / dV accumulators across the branch and spilled.
+    int wa = nqt, wb = qt0;
+    if (!per_row) {
+        if (u_ke > kw0 && max(u_ks, 0) < kw0 + 32) { wa = qt0; wb = nqt; }
+    } else {
+        for (int t0 = qt0; t0 < nqt; t0 += 64) {
+            const int t = t0 + lane;
+            const bool hit = t < nqt && agg[4 * t + 3] > kw0 && max(agg[4 * t], 0) < kw0 + 32;
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                wa = min(wa, t0 + (int)__builtin_ctzll(m));
+                wb = max(wb, t0 + 64 - (int)__builtin_clzll(m));
             }
         }
-        if (ahead) {
-            store_aux(s2);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        wa = __builtin_amdgcn_readfirstlane(wa); wb = __builtin_amdgcn_readfirstlane(wb);
+    }
+    if (wa >= wb) { wa = nqt; wb = nqt; }
+
+    DkvBlk blk;
+    int s_ = 0;
+    unsigned rfa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rfa[s] = rfb[s];
+    // middle of an iteration: tile qt + 1 must have landed for everybody; then the slot of tile qt - 1 is refilled
+    auto ring_step = [&](int qt) {
+        const int left = nqt - 1 - qt;                          // tiles after this one
+        // in flight here: tiles qt+1 .. qt+R-2 (those that exist); tile qt+1 must land, the younger ones may stay out
+        const int stay = min(left, R - 2) - 1;
+        if (stay >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (stay == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (qt + R - 1 < nqt) load_tile(qt + R - 1, (s_ + R - 1) % R);
+    };
+    for (int qt = qt0; qt < wa; ++qt) {                          // nothing to compute yet
+        ring_step(qt);
+        s_ = (s_ + 1 == R) ? 0 : s_ + 1;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rfa[s] = rfb[s] + s_ * 2 * TILE_BYTES;
+    if (wa < wb) dkv_issue<0>(blk, rfa, auxb + s_ * 1024);
+
+    // One 32-row block.  Order of issue: [this block's 16 reads have landed] the 16 transposed reads of dO / Q | S' and dP'
+    // chains (8 MFMAs; the transposed reads land under them) | exp2 / multiply / pack | the NEXT block's 16 reads | dV^T /
+    // dK^T chains (8 MFMAs; the next block's reads land under them).  NQB: the next block's index inside its tile; NRF /
+    // NAUX: its fragment / constant addresses.
+#define DKV_BLOCK(QB, NQB, NRF, NAUX)                                                                                    \
+    {                                                                                                                    \
+        dkv_wait(blk);                                                                                                   \
+        s16x4 gfr[4][2], qfr[4][2];                                                                                      \
+        tr_issue<TILE_BYTES, 2 * QB>(tra, s_ * 2 * TILE_BYTES, gfr);                                                     \
+        tr_issue<0, 2 * QB>(tra, s_ * 2 * TILE_BYTES, qfr);                                                              \
+        f32x16 st = cat16(blk.cs), dp = cat16(blk.cd);                                                                   \
+        if (cls == CLS_LANE) {           /* one interval for the whole tile: keys outside it start from -inf -> p = 0 */ \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) st[r] = lane_ok ? st[r] : -__builtin_inff();                  \
+        }                                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                  \
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                                 \
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                                 \
+        }                                                                                                                \
+        if (cls != CLS_GENERAL) {                                                                                        \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+                const float pe = __builtin_amdgcn_exp2f(st[r]);                                                          \
+                st[r] = pe;                                                                                              \
+                dp[r] = pe * dp[r];                                                                                      \
+            }                                                                                                            \
+        } else {              /* rows with different intervals, empty intervals, rows past Nq: per-element masks */      \
+            const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);                                                \
+            const int* ai = (const int*)(af + 128);                                                                      \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
+                const int qb0 = QB * 32 + 8 * g + 4 * hh;                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                    const int r = 4 * g + e;                                                                             \
+                    int rks = ai[per_row ? qb0 + e : 0], rke = min(ai[64 + (per_row ? qb0 + e : 0)], p.Nk);              \
+                    const bool flat = rke <= rks;                          /* empty interval: p = 1 / Nk, dS = 0 */      \
+                    if (flat) { rks = 0; rke = p.Nk; }                                                                   \
+                    const bool ok = (qt * 64 + qb0 + e < p.Nq) && (kidx >= rks) && (kidx < rke);                         \
+                    const float pe = ok ? __builtin_amdgcn_exp2f(flat ? af[qb0 + e] : st[r]) : 0.f;                      \
+                    st[r] = pe;                                                                                          \
+                    dp[r] = flat ? 0.f : pe * dp[r];                                                                     \
+                }                                                                                                        \
+            }                                                                                                            \
+        }                                                                                                                \
+        const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1), ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                     \
+        lgkm_wait_tied<0>(gfr);                                                                                          \
+        lgkm_wait_tied<0>(qfr);                                                                                          \
+        dkv_issue<NQB>(blk, NRF, NAUX);                                                                                  \
+        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[db][0], gfr[db][1]), pf0, dvt[db], 0, 0, 0);     \
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[db][0], qfr[db][1]), ds0, dkt[db], 0, 0, 0);     \
+        }                                                                                                                \
+        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 + db][0], gfr[2 + db][1]), pf1, dvt[db], 0, 0, 0); \
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 + db][0], qfr[2 + db][1]), ds1, dkt[db], 0, 0, 0); \
+        }                                                                                                                \
+    }
+
+    constexpr int CLS_FULL = 1, CLS_LANE = 2, CLS_GENERAL = 3;
+    for (int qt = wa; qt < wb; ++qt) {
+        // What this q tile is for this wave's 32 keys (scalar decisions): every row sees all of them (full); all 64 rows
+        // share ONE interval (per-lane mask); anything else (per-element masks).
+        int t_ks, t_ks2, t_ke, t_ke2;
+        if (per_row) {
+            // (flat rows carry ks = -1, rows beyond Nq carry ks = INT_MAX: both force the general path)
+            t_ks = __builtin_amdgcn_readfirstlane(agg[4 * qt]); t_ks2 = __builtin_amdgcn_readfirstlane(agg[4 * qt + 1]);
+            t_ke2 = __builtin_amdgcn_readfirstlane(agg[4 * qt + 2]); t_ke = __builtin_amdgcn_readfirstlane(agg[4 * qt + 3]);
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool whole = qt * 64 + 64 <= p.Nq;
+            t_ks = u_ks; t_ks2 = whole ? u_ks : INT_MAX; t_ke = u_ke; t_ke2 = whole ? u_ke : 0;
         }
-        lds_barrier();
-        s_ = (s_ == 2) ? 0 : s_ + 1;
+        // t_ks / t_ks2 = min / max of the rows' interval starts, t_ke2 / t_ke = min / max of their ends
+        int cls;
+        if (t_ks >= 0 && t_ks2 <= kw0 && t_ke2 >= kw0 + 32) cls = CLS_FULL;
+        else if (t_ks >= 0 && t_ks == t_ks2 && t_ke == t_ke2) cls = CLS_LANE;
+        else cls = CLS_GENERAL;
+        const bool lane_ok = kidx >= t_ks && kidx < t_ke;
+        DKV_BLOCK(0, 1, rfa, auxb + s_ * 1024)
+        ring_step(qt);
+        // block 1 prefetches block 0 of the next tile (after the last tile: a harmless read of a stale slot)
+        const int sn = (s_ + 1 == R) ? 0 : s_ + 1;
+        unsigned rfn[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rfn[s] = rfb[s] + sn * 2 * TILE_BYTES;
+        DKV_BLOCK(1, 0, rfn, auxb + sn * 1024)
+        s_ = sn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rfa[s] = rfn[s];
+    }
+#undef DKV_BLOCK
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last (unused) prefetch
+    for (int qt = wb; qt < nqt; ++qt) {                          // nothing left to compute
+        ring_step(qt);
+        s_ = (s_ + 1 == R) ? 0 : s_ + 1;
     }
     if (kidx < p.Nk) {
-        store_rows_bf16(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * 64, dkt, 1.f, hh);
+        store_rows_bf16(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * 64, dkt, p.scale, hh);
         store_rows_bf16(p.dV + (long)b * p.dv_bs + (long)krow * p.dv_rs + h * 64, dvt, 1.f, hh);
     }
 }
@@ -694,13 +820,13 @@ bool check(const AttnArgs& a) {
 }  // namespace
 
 extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
-                                const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, float* LSE,
+                                const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE,
                                 const int* ks, const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk,
                                 float scale, hipStream_t stream) {
     AttnArgs a{};
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
-    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
@@ -710,7 +836,7 @@ extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void*
 }
 
 extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
-                                const void* V, long v_bs, long v_rs, const void* O, long o_bs, long o_rs,
+                                const void* V, long v_bs, long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo,
                                 const void* dO, long do_bs, long do_rs, const float* LSE, float* DELTA,
                                 void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                                 void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs,
@@ -720,7 +846,7 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
     a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
-    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo;
     a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA; a.DELTA_OUT = DELTA;
     a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
@@ -728,9 +854,12 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
     if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
-    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
+#ifndef ATT_ONLY
+#define ATT_ONLY 0                      // timing builds: 1 = dQ kernel only, 2 = dK / dV kernel only
+#endif
+    if (ATT_ONLY != 2) { EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a); }
     LAUNCH_CHECK();
-    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128)), dim3(256), 0, stream, a);
+    if (ATT_ONLY != 1) { EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128)), dim3(256), 0, stream, a); }
     LAUNCH_CHECK();
     return EGO_OK;
 }

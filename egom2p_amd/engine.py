@@ -48,8 +48,16 @@ class _Lin:
 
 
 class Engine:
-    def __init__(self, cfg: ModelCfg, device="cuda:0", max_batch: int = 1, n_enc: int = 2048, n_dec: int = 2048):
+    def __init__(self, cfg: ModelCfg, device="cuda:0", max_batch: int = 1, n_enc: int = 2048, n_dec: int = 2048,
+                 attn_o_residual: str = "cross"):
+        """attn_o_residual: which attention sites also keep the bf16 rounding residual of their output so that the
+        backward's delta = rowsum(dO o O) is formed from O to ~16 bits ("cross": the cross-attention sites - where, with
+        near-uniform attention over ~2000 context keys, the plain flash-style delta put 3.5 % error on the query-path
+        gradients; "all"; "none").  Costs one more bf16 [rows, D] write + read per site (~0.5 % of a step for "cross")."""
         L.load()  # fail loudly if the HIP library is missing
+        if attn_o_residual not in ("cross", "all", "none"):
+            raise ValueError("attn_o_residual must be 'cross', 'all' or 'none'")
+        self.attn_o_residual = attn_o_residual
         if cfg.dim % 128 or cfg.head_dim != 64:
             raise L.EgoHipError(f"engine needs dim % 128 == 0 and head_dim == 64 (got dim={cfg.dim}, head_dim={cfg.head_dim})")
         self.cfg = cfg
@@ -342,13 +350,16 @@ class Engine:
 
         def enc_layer():
             return dict(x=e(RN, D, dt=F32), xm=e(RN, D, dt=F32), ln1=e(RN, D), qkv=e(RN, 3 * D), ao=e(RN, D),
+                        ao_lo=e(RN, D) if self.attn_o_residual == "all" else None,
                         lse=e(B, H, N, dt=F32), st1=e(2, RN, dt=F32), ln2=e(RN, D), ab=e(RN, 2 * Fp), h=e(RN, Fp),
                         st2=e(2, RN, dt=F32))
 
         def dec_layer():
             return dict(x=e(RM, D, dt=F32), x1=e(RM, D, dt=F32), x2=e(RM, D, dt=F32), ln1=e(RM, D), qkv=e(RM, 3 * D),
-                        ao=e(RM, D), lse=e(B, H, M, dt=F32), st1=e(2, RM, dt=F32), qn=e(RM, D), q=e(RM, D),
+                        ao=e(RM, D), ao_lo=e(RM, D) if self.attn_o_residual == "all" else None, lse=e(B, H, M, dt=F32),
+                        st1=e(2, RM, dt=F32), qn=e(RM, D), q=e(RM, D),
                         stq=e(2, RM, dt=F32), cn=e(RN, D), kv=e(RN, 2 * D), stc=e(2, RN, dt=F32), xo=e(RM, D),
+                        xo_lo=e(RM, D) if self.attn_o_residual != "none" else None,
                         lse_x=e(B, H, M, dt=F32), ln2=e(RM, D), ab=e(RM, 2 * Fp), h=e(RM, Fp), st2=e(2, RM, dt=F32))
 
         self.enc = [enc_layer() for _ in range(cfg.encoder_depth)]
@@ -425,18 +436,20 @@ class Engine:
                 self.side.wait_event(ev)
                 run()
 
-    def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk):
+    def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk, o_lo=None):
         D = self.D
         ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, lse, ks, ke, r_bs, r_rs,
-                     B, self.H, Nq, Nk, self.scale)
+                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr())
 
-    def _attn_bwd(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, do_t, lse, dq_t, dkv_t, ks, ke, r_bs, r_rs, B, Nq, Nk):
+    def _attn_bwd(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, do_t, lse, dq_t, dkv_t, ks, ke, r_bs, r_rs, B, Nq, Nk,
+                  o_lo=None):
         D = self.D
         ops.attn_bwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, do_t.data_ptr(), Nq * D, D,
                      lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
-                     kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale)
+                     kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale,
+                     o_lo=None if o_lo is None else o_lo.data_ptr())
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
@@ -486,7 +499,8 @@ class Engine:
             self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln1"], w["qkv"], RN)
             # key-padding mask = one interval [0, n_valid) per SAMPLE (the per-row copies ce["ks"/"ke"] hold the same
             # numbers): the uniform form lets the attention kernels walk one (batch, head) pair per XCD (L2-resident K / V)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N,
+                       o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
             ops.layernorm_fwd(w["xm"][:RN], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
             self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RN)
@@ -502,13 +516,15 @@ class Engine:
             nxt = self.dec[i + 1]["x"] if i + 1 < cfg.decoder_depth else self.y_out
             ops.layernorm_fwd(w["x"][:RM], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln1"], w["qkv"], RM)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M)
+            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M,
+                       o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
             ops.layernorm_fwd(w["x1"][:RM], self.p[f"{pre}.query_norm.weight"], w["qn"], w["stq"][0], w["stq"][1], eps=cfg.eps)
             self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
             ops.layernorm_fwd(self.ctx[:RN], self.p[f"{pre}.context_norm.weight"], w["cn"], w["stc"][0], w["stc"][1], eps=cfg.eps)
             self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
-            self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N)
+            self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N,
+                       o_lo=w["xo_lo"])
             self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["xo"], w["x2"], RM, L.EPI_RESID, R=w["x1"])
             ops.layernorm_fwd(w["x2"][:RM], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
             self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RM)
@@ -555,7 +571,8 @@ class Engine:
         r_bs = Nq if r_bs is None else r_bs
         dao, dqkv, dln = self.t_d, self.t_3d, self.t_d2
         self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
-        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq)
+        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq,
+                       o_lo=w["ao_lo"])
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
@@ -606,7 +623,7 @@ class Engine:
             dxo, dq, dkv, dln = self.t_d, self.t_d2, self.t_2d, self.t_d
             self._lin_bwd(f"{pre}.cross_attn.proj.weight", dres_b, w["xo"], dxo, RM)
             self._attn_bwd(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], dxo, w["lse_x"], dq, dkv, self.zero_b, ce["n_valid"],
-                           1, 0, B, M, N)
+                           1, 0, B, M, N, o_lo=w["xo_lo"])
             self._lin_bwd(f"{pre}.cross_attn.q.weight", dq, w["qn"], dln, RM)
             nb = self._ring_next()
             ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,

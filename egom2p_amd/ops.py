@@ -85,14 +85,15 @@ def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
     return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))
 
 
-def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):
-    check(L.load().ego_attn_fwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, _p(lse), _p(ks), _p(ke),
+def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None):
+    """o_lo (optional device pointer, laid out like o): receives the bf16 rounding residual of the output"""
+    check(L.load().ego_attn_fwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
                                     r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_fwd_d64")
 
 
 def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
-             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale):
-    check(L.load().ego_attn_bwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs,
+             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None):
+    check(L.load().ego_attn_bwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                     _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
                                     _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_bwd_d64")
 

@@ -125,12 +125,18 @@ int ego_gemm_tn_plan(int Ni, int Nj, int M, long ldp, long ldq, long slab_elems,
 /* Fused attention, head_dim 64 (Attention / CrossAttention, egom2p_utils.py:185-205, 222-244).
  * Element (b, row, head h, d) of X at X + b * x_bs + row * x_rs + h * 64 + d.  ks/ke: allowed key
  * interval of query row (b, q) at [b * r_bs + q * r_rs] (r_rs = 0: one interval per sample).
- * LSE: fp32 [B, H, Nq], log2 domain. */
+ * LSE: fp32 [B, H, Nq], MINUS the log2-domain log-sum-exp of the scaled scores (an opaque hand-over from the forward to
+ * the backward, which uses it - and DELTA, MINUS rowsum(dO o O), written by the backward's first kernel - as the initial
+ * accumulator of its score / dP MFMA chains).
+ * O_lo (optional, NULL = off; laid out like O): the forward also stores bf16(o - bf16(o)) and the backward forms
+ * delta = rowsum(dO o (O + O_lo)) - torch's softmax backward gets its row sums from the fp32 probabilities, the
+ * flash-style rowsum(dO o O) from the bf16-rounded output loses that (3.5 % on the cross-attention query gradients at
+ * N = 2048; with O_lo they are at the tensor's own bf16 noise). */
 int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
-                     long v_rs, void* O, long o_bs, long o_rs, float* LSE, const int* ks, const int* ke, long r_bs,
-                     long r_rs, int B, int H, int Nq, int Nk, float scale, hipStream_t stream);
+                     long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks, const int* ke,
+                     long r_bs, long r_rs, int B, int H, int Nq, int Nk, float scale, hipStream_t stream);
 int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
-                     long v_rs, const void* O, long o_bs, long o_rs, const void* dO, long do_bs, long do_rs,
+                     long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo, const void* dO, long do_bs, long do_rs,
                      const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                      void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
                      int Nq, int Nk, float scale, hipStream_t stream);

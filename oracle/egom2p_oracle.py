@@ -13,6 +13,8 @@ mode='fp32'  : plain fp32 (the truth the goldens were produced in).
 mode='bf16'  : inserts bf16 roundings where CUDA autocast(bf16) would (GEMM-class inputs and
                outputs bf16; softmax / layer_norm / cross_entropy fp32; residual stream fp32)
                - SURVEY.md section 2.2.  Used as the tight comparison for the HIP kernels.
+mode='bf16_bwd': the same, and gradients are rounded to bf16 at the same points (what autocast's
+               backward does: the gradient of a bf16 tensor is bf16).
 """
 from __future__ import annotations
 
@@ -24,8 +26,24 @@ import torch
 import torch.nn.functional as F
 
 
+class _RoundBoth(torch.autograd.Function):
+    """bf16 round trip in the forward AND on the gradient: a tensor that lives in bf16 under autocast receives a bf16
+    gradient (the backward of a bf16 op produces bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
 def _r(x: torch.Tensor, mode: str) -> torch.Tensor:
-    """Round to bf16 and come back (autograd: straight-through like a dtype cast)."""
+    """Round to bf16 and come back.  mode 'bf16': straight-through gradient (forward roundings only);
+    mode 'bf16_bwd': the gradient is rounded to bf16 too, as the backward of autocast(bf16) does."""
+    if mode == "bf16_bwd":
+        return _RoundBoth.apply(x)
     if mode != "bf16":
         return x
     return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
@@ -132,7 +150,8 @@ def attention_ranges(dam: np.ndarray, modid_pre: np.ndarray, pad: np.ndarray):
 # transformer blocks
 # ----------------------------------------------------------------------------------------
 
-_NEG = {"fp32": -torch.finfo(torch.float32).max, "bf16": -float(torch.finfo(torch.bfloat16).max)}
+_NEG = {"fp32": -torch.finfo(torch.float32).max, "bf16": -float(torch.finfo(torch.bfloat16).max),
+        "bf16_bwd": -float(torch.finfo(torch.bfloat16).max)}
 
 
 def _softmax_attn(q, k, v, blocked, scale, mode):

@@ -78,7 +78,12 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
             eng.backward(1.0, bucket_done=red.on_bucket)
             red.finish()
             torch.cuda.synchronize()
-            assert torch.equal(eng.G, plain)
+            # weight gradients come out of deterministic split-K GEMMs: bitwise; the embedding / bias / LayerNorm-weight
+            # gradients are summed with float atomics (arrival order): equal to rounding
+            for n in ("encoder.0.attn.qkv.weight", "decoder.1.mlp.fc2.weight", "decoder.0.cross_attn.kv.weight", "decoder_proj_context.weight"):
+                lo, cnt, _ = eng.offsets[n]
+                assert torch.equal(eng.G[lo:lo + cnt], plain[lo:lo + cnt]), n
+            assert float((eng.G - plain).double().norm() / plain.double().norm()) < 1e-6
             spans = sorted(red.last_launched)
             assert spans[0][0] == 0 and spans[-1][1] == eng.n_flat
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])), spans
