@@ -26,6 +26,18 @@ class CompactDesc(C.Structure):
     ]
 
 
+MAX_MIX = 8
+
+
+class BudgetDesc(C.Structure):
+    _fields_ = [
+        ("n_mods", i32), ("n_mix", i32),
+        ("in_alpha", (f32 * MAX_MODS) * MAX_MIX), ("tgt_alpha", (f32 * MAX_MODS) * MAX_MIX), ("mix_weight", f32 * MAX_MIX),
+        ("max_tokens", i32 * MAX_MODS), ("min_tokens", i32 * MAX_MODS), ("not_seq", i32 * MAX_MODS),
+        ("n_in_lo", i32), ("n_in_hi", i32), ("n_tgt_lo", i32), ("n_tgt_hi", i32), ("max_tries", i32),
+    ]
+
+
 class EmbedDesc(C.Structure):
     _fields_ = [
         ("table", vp * MAX_MODS), ("pos", vp * MAX_MODS), ("mod", vp * MAX_MODS), ("base_vec", vp),
@@ -36,7 +48,7 @@ class EmbedDesc(C.Structure):
 class EmbedBwdDesc(C.Structure):
     _fields_ = [
         ("dtable", vp * MAX_MODS), ("dmod", vp * MAX_MODS), ("dbase", vp), ("dx", vp), ("d2", vp),
-        ("slot", vp), ("tok", vp), ("rows", i64), ("D", i32), ("n_mods", i32),
+        ("slot", vp), ("tok", vp), ("rows", i64), ("D", i32), ("n_mods", i32), ("touched", vp * MAX_MODS),
     ]
 
 
@@ -46,6 +58,9 @@ _SIGS = {
     "ego_compact": [C.POINTER(CompactDesc), i32, vp],
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
     "ego_embed_bwd": [C.POINTER(EmbedBwdDesc), vp],
+    "ego_rows_compact": [vp, i32, i32, vp, vp, vp],
+    "ego_rows_gather": [vp, vp, vp, i32, i32, vp, vp],
+    "ego_rows_scatter": [vp, vp, vp, i32, i32, vp, i32, vp],
     "ego_loss_perm": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
@@ -56,6 +71,7 @@ _SIGS = {
                          i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
                          vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
+    "ego_budget_dirichlet": [C.POINTER(BudgetDesc), vp, i32, vp, vp, vp],
     "ego_clip_synth": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_swiglu_fwd": [vp, vp, i64, i32, vp],
     "ego_swiglu_bwd": [vp, vp, vp, i64, i32, vp],

@@ -85,4 +85,6 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
     "ego_L_1152_2e_2d": ModelCfg("ego_L_1152_2e_2d", 1152, 2, 2, 18),       # ego-L width (BASELINE config 5) at parity-test depth
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),
+    # config 4 (rgb -> depth generation) at ego-b width: D = 768, 12 heads of 64, F = 2048, at parity-test depth
+    "ego_b_gen_2e_2d": ModelCfg("ego_b_gen_2e_2d", 768, 2, 2, 12, modalities=("tok_rgb", "tok_depth")),
 }

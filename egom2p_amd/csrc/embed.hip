@@ -275,6 +275,7 @@ struct EmbedBwdArgs {
     const float* dx; const float* d2;   // [rows, D]; d2 may be null
     const int* slot; const int* tok;
     long rows; int D, n_mods;
+    unsigned char* touched[EGO_MAX_MODS];   // optional [V]: set to 1 for every table row that receives a gradient
 };
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
@@ -291,7 +292,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
         float* trow = nullptr;
 #pragma unroll
         for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) trow = a.dtable[m];
-        if (trow) trow += (long)a.tok[row] * a.D;
+        if (trow) {
+            trow += (long)a.tok[row] * a.D;
+            unsigned char* fl = nullptr;
+#pragma unroll
+            for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) fl = a.touched[m];
+            if (fl && lane == 0) fl[a.tok[row]] = 1;
+        }
         // one dword per lane, 256 contiguous bytes per wave instruction: the shape global float
         // atomics run at full rate with
         for (int col = lane; col < a.D; col += 64) {
@@ -317,7 +324,90 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row lists for the sparse exchange of embedding-table gradients: with few clips per
+// optimiser step only a few thousand of a table's 64,000 rows carry a gradient, and ranks exchange (row id, row) lists
+// instead of all-reducing the dense table.
+// ---------------------------------------------------------------------------------------------
+// touched[V] -> ascending row list (at most cap entries), count; the flags are cleared for the next step.  One workgroup.
+__global__ __launch_bounds__(1024) void rows_compact_kernel(unsigned char* __restrict__ touched, int V, int cap,
+                                                            int* __restrict__ rows, int* __restrict__ count) {
+    __shared__ int s_w[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < V; base += 1024) {
+        const int i = base + tid;
+        const bool on = i < V && touched[i] != 0;
+        if (on) touched[i] = 0;
+        const unsigned long long ball = __ballot(on);
+        if (lane == 0) s_w[wave] = __popcll(ball);
+        __syncthreads();
+        int pre = s_run;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        const int pos = pre + __popcll(ball & ((1ull << lane) - 1ull));
+        if (on && pos < cap) rows[pos] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_w[w]; s_run += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = min(s_run, cap) | (s_run > cap ? 0x40000000 : 0);      // bit 30: the list did not fit (caller's cap too small)
+    for (int i = min(s_run, cap) + tid; i < cap; i += 1024) rows[i] = -1;
+}
+
+// out[i, :] = T[rows[i], :] for i < count, 0 for count <= i < cap      (one wave per row, 16 bytes per lane)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ T, const int* __restrict__ rows,
+                                                          const int* __restrict__ count, int cap, int D, float* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= cap) return;
+    const int n = *count & 0x3fffffff;
+    const int r = i < n ? rows[i] : -1;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = r >= 0 ? *(const f32x4*)(T + (long)r * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(out + (long)i * D + c) = v;
+    }
+}
+
+// T[rows[i], :] = (add ? T[rows[i], :] : 0) + src[i, :] for i < count; rows of one list are distinct, so plain stores
+__global__ __launch_bounds__(256) void rows_scatter_kernel(float* __restrict__ T, const int* __restrict__ rows, const int* __restrict__ count,
+                                                           int cap, int D, const float* __restrict__ src, int add) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= cap) return;
+    const int n = min(*count & 0x3fffffff, cap);
+    if (i >= n) return;
+    const int r = rows[i];
+    if (r < 0) return;
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 v = src ? *(const f32x4*)(src + (long)i * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};     // no source: clear the rows
+        if (add) v += *(const f32x4*)(T + (long)r * D + c);
+        *(f32x4*)(T + (long)r * D + c) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int ego_rows_compact(void* touched, int V, int cap, int* rows, int* count, hipStream_t stream) {
+    if (V <= 0 || cap <= 0) return EGO_ERR_ARG;
+    EGO_LAUNCH(rows_compact_kernel, dim3(1), dim3(1024), 0, stream, (unsigned char*)touched, V, cap, rows, count);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_rows_gather(const float* table, const int* rows, const int* count, int cap, int D, float* out, hipStream_t stream) {
+    if (cap <= 0 || D % 4) return EGO_ERR_ARG;
+    EGO_LAUNCH(rows_gather_kernel, dim3((cap + 3) / 4), dim3(256), 0, stream, table, rows, count, cap, D, out);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_rows_scatter(float* table, const int* rows, const int* count, int cap, int D, const float* src, int add,
+                                hipStream_t stream) {
+    if (cap <= 0 || D % 4) return EGO_ERR_ARG;
+    EGO_LAUNCH(rows_scatter_kernel, dim3((cap + 3) / 4), dim3(256), 0, stream, table, rows, count, cap, D, src, add);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
 
 extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream) {
     if (!d || d->n_mods <= 0 || d->n_mods > EGO_MAX_MODS || B <= 0) return EGO_ERR_ARG;
@@ -371,6 +461,7 @@ extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
     for (int m = 0; m < EGO_MAX_MODS; ++m) { a.dtable[m] = d->dtable[m]; a.dmod[m] = d->dmod[m]; }
     a.dbase = d->dbase; a.dx = d->dx; a.d2 = d->d2; a.slot = d->slot; a.tok = d->tok;
     a.rows = d->rows; a.D = d->D; a.n_mods = d->n_mods;
+    for (int m = 0; m < EGO_MAX_MODS; ++m) a.touched[m] = d->touched[m];
     const size_t lds = (size_t)(d->n_mods + 1) * d->D * sizeof(float);
     if (lds > 64 * 1024) return EGO_ERR_ARG;
     EGO_LAUNCH(embed_bwd_kernel, dim3((unsigned)((d->rows + 63) / 64)), dim3(256), lds, stream, a);

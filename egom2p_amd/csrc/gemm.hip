@@ -860,8 +860,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
     long moff = 0;
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
     const int tiles_j = (p.Nj + 255) / 256, ntile = ((p.Ni + 255) / 256) * tiles_j;      // a last tile may be half empty
-    const int split = blockIdx.x / ntile;
-    const int t = xcd_remap(blockIdx.x % ntile, ntile);
+    // Workgroups b, b + 8, .. share an XCD (round-robin dispatch): each XCD takes a CONTIGUOUS run of (split, tile) pairs,
+    // so the tiles of one split - which stream the same 64-row steps of P and Q - run side by side on one L2 and those
+    // rows are fetched from HBM once per XCD-resident split instead of once per tile (speed only, never correctness).
+#ifndef TN_MAP
+#define TN_MAP 1
+#endif
+    const int lin = TN_MAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int split = lin / ntile;
+    const int t = TN_MAP ? lin % ntile : xcd_remap(lin % ntile, ntile);
     const int i0 = (t / tiles_j) * 256, j0 = (t % tiles_j) * 256;
     const int nsteps = (M + BK - 1) / BK;
     const int per = (nsteps + p.splits - 1) / p.splits;

@@ -16,15 +16,17 @@ with the gloo backend (tests/test_dp_gloo.py).
 from __future__ import annotations
 
 import contextlib
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0, force: bool = False):
+    def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0, force: bool = False,
+                 skip: Sequence[str] = ()):
         self.G = flat_grad
+        self.skip = set(skip)                   # bucket names exchanged by other means (SparseTableExchange)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: rehearse the path with one rank
@@ -38,7 +40,7 @@ class GradBucketReducer:
 
     # buckets arrive tail-first and contiguous: [lo, hi) then [lo', lo) ...; merge until >= cap
     def on_bucket(self, name: str, lo: int, hi: int):
-        if not self.active:
+        if not self.active or name in self.skip:
             return
         if self._pending is None:
             self._pending = (lo, hi)
@@ -77,6 +79,99 @@ class GradBucketReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works.clear()
         self.last_launched, self.launched = self.launched, []
+
+
+class SparseTableExchange:
+    """Row-list exchange of embedding-table gradients.
+
+    DDP all-reduces the dense 64000 x 768 encoder tables (run_training_egom2p.py:514: 2 x 197 MB of the 1.585 GB), although
+    a step with few clips per GPU touches only (clips x kept tokens) rows.  Here every rank compacts the rows it touched
+    (flags set by the embedding backward), all-gathers (row ids, rows) padded to `cap_rows`, and sums all ranks' rows in
+    rank order into the table - the same result as the dense sum (identical on every rank: one fixed order), moving
+    (world - 1) * cap_rows rows instead of 2 (world - 1) / world * V.  `worth_it` is that byte comparison.
+
+    Works on CPU tensors too (gloo rehearsal in tests/test_dp_gloo.py); on the GPU the compaction / gather / scatter are
+    the ego_rows_* kernels."""
+
+    def __init__(self, tables, cap_rows: int, process_group=None):
+        """tables: list of (grad view [V, D] fp32, touched flags uint8 [V])."""
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.tables = []
+        for g, touched in tables:
+            V, D = g.shape
+            cap = min(int(cap_rows), V)
+            dev = g.device
+            self.tables.append(dict(g=g, touched=touched, cap=cap,
+                                    rows=torch.full((cap,), -1, dtype=torch.int32, device=dev), count=torch.zeros(1, dtype=torch.int32, device=dev),
+                                    send=torch.zeros(cap, D, dtype=torch.float32, device=dev),
+                                    all_rows=torch.empty(self.world, cap, dtype=torch.int32, device=dev),
+                                    all_count=torch.empty(self.world, 1, dtype=torch.int32, device=dev),
+                                    all_send=torch.empty(self.world, cap, D, dtype=torch.float32, device=dev)))
+
+    @staticmethod
+    def worth_it(V: int, D: int, cap_rows: int, world: int) -> bool:
+        gather = (world - 1) * min(cap_rows, V) * (D * 4 + 4)
+        dense = 2.0 * (world - 1) / world * V * D * 4
+        return world > 1 and gather < dense
+
+    # --- the three primitives: HIP kernels on the GPU, torch indexing on CPU tensors (gloo rehearsal only)
+    @staticmethod
+    def _compact(t):
+        if t["g"].is_cuda:
+            from . import ops
+            ops.rows_compact(t["touched"], t["cap"], t["rows"], t["count"])
+        else:
+            idx = torch.nonzero(t["touched"]).flatten().to(torch.int32)
+            n = min(idx.numel(), t["cap"])
+            t["rows"].fill_(-1)
+            t["rows"][:n] = idx[:n]
+            t["count"][0] = n | (0x40000000 if idx.numel() > t["cap"] else 0)
+            t["touched"].zero_()
+
+    @staticmethod
+    def _gather(t):
+        if t["g"].is_cuda:
+            from . import ops
+            ops.rows_gather(t["g"], t["rows"], t["count"], t["cap"], t["send"])
+        else:
+            n = int(t["count"][0]) & 0x3fffffff
+            t["send"].zero_()
+            t["send"][:n] = t["g"][t["rows"][:n].long()]
+
+    @staticmethod
+    def _scatter(t, rows, count, src, add):
+        if t["g"].is_cuda:
+            from . import ops
+            ops.rows_scatter(t["g"], rows, count, t["cap"], src, add)
+        else:
+            n = int(count[0]) & 0x3fffffff
+            idx = rows[:n].long()
+            if src is None:
+                t["g"][idx] = 0
+            elif add:
+                t["g"][idx] += src[:n]
+            else:
+                t["g"][idx] = src[:n]
+
+    def exchange(self):
+        """Call once per optimiser step, after the last backward (the touched flags accumulate over micro-batches)."""
+        for t in self.tables:
+            self._compact(t)
+            self._gather(t)
+            if self.world > 1:
+                dist.all_gather_into_tensor(t["all_rows"].view(-1), t["rows"], group=self.pg)
+                dist.all_gather_into_tensor(t["all_count"].view(-1), t["count"], group=self.pg)
+                dist.all_gather_into_tensor(t["all_send"].view(-1), t["send"].view(-1), group=self.pg)
+            else:
+                t["all_rows"][0].copy_(t["rows"]); t["all_count"][0].copy_(t["count"]); t["all_send"][0].copy_(t["send"])
+            self._scatter(t, t["rows"], t["count"], None, False)            # own rows: cleared, then every rank's rows in rank order
+            for r in range(self.world):
+                self._scatter(t, t["all_rows"][r], t["all_count"][r], t["all_send"][r], True)
+
+    def overflowed(self) -> bool:
+        """Host-side check (one sync): did any rank touch more rows than `cap_rows` in the last exchange?"""
+        return any(bool((t["all_count"] & 0x40000000).any().item()) for t in self.tables)
 
 
 class DataParallel(torch.nn.Module):

@@ -663,7 +663,7 @@ class Engine:
         # encoder input embeddings: token rows, mod_emb (emb is used twice: x = tok + emb and context += emb)
         ops.embed_bwd([self.g[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
                       [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, dxe, self.dctx,
-                      ce["slot"], ce["tok"], RN, D)
+                      ce["slot"], ce["tok"], RN, D, touched=getattr(self, "touched", None))
         done("mod_emb")
         for m in reversed(mods):
             done(f"enc_table.{m.name}")
@@ -672,6 +672,16 @@ class Engine:
 
     def zero_grad(self):
         self.G.zero_()
+
+    def track_touched_table_rows(self, on: bool = True):
+        """Let the embedding backward flag every encoder-table row that receives a gradient (uint8 [V] per table,
+        accumulated over micro-batches, consumed and cleared by dp.SparseTableExchange).  Returns
+        [(gradient view [V, D], flags)] for the encoder tables, in modality order."""
+        if not on:
+            self.touched = None
+            return []
+        self.touched = [torch.zeros(m.vocab_size, device=self.dev, dtype=torch.uint8) for m in self.mods]
+        return [(self.g[f"encoder_embeddings.{m.name}.token_emb.weight"], self.touched[i]) for i, m in enumerate(self.mods)]
 
     def resize_workspaces(self, max_batch: int, n_enc: int, n_dec: int):
         """Re-allocate the activation workspaces for another (batch, N, M); parameters are untouched."""

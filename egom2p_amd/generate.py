@@ -109,9 +109,10 @@ class GenerationSampler:
         self.use_graphs = use_graphs           # replay each encoder-decoder pass from a captured hipGraph
 
     # one encoder-decoder pass (forward_enc_dec_roar_batched, generate.py:747-766) ---------------------
-    def _logits(self, mod_dict, target_mod, mod_pos):
+    def _logits(self, mod_dict, target_mod, mod_pos, n_enc: Optional[int] = None, ws: Optional[dict] = None):
+        """n_enc given: no host sync (the caller knows the kept-row count, e.g. from the schedule); ws: workspace to use."""
         eng = self.engine
-        enc, n_enc = {}, 0
+        enc = {}
         for m in eng.mods:
             if m.name not in mod_dict:
                 continue
@@ -121,39 +122,52 @@ class GenerationSampler:
             mask = d["input_mask"].reshape(B, -1).to(eng.dev, torch.bool)
             enc[m.name] = (ids, mask)
         # rows kept by forward_mask_encoder_generation = max unmasked count over the batch (:413-415)
-        n_enc = int(torch.stack([(~v[1]).sum(1) for v in enc.values()]).sum(0).max().item()) if enc else 0
+        if n_enc is None:
+            n_enc = int(torch.stack([(~v[1]).sum(1) for v in enc.values()]).sum(0).max().item()) if enc else 0
+        if ws is not None:
+            return eng.infer_logits(enc, n_enc, target_mod, mod_pos, ws=ws)
         if self.use_graphs:
             return eng.infer_logits_graphed(enc, n_enc, target_mod, mod_pos).clone()
         return eng.infer_logits(enc, n_enc, target_mod, mod_pos)
 
-    def roar_order(self, target_mask: torch.Tensor, num_select: int, seed: Optional[int]) -> torch.Tensor:
+    def roar_order(self, target_mask: torch.Tensor, num_select: int, seed: Optional[int], noise: Optional[torch.Tensor] = None,
+                   n_dec: Optional[int] = None) -> torch.Tensor:
         """Positions decoded in this step (forward_mask_decoder_roar, :481-516): unmasked targets in a random
-        order shared by the batch, the first `num_select` of them."""
+        order shared by the batch, the first `num_select` of them.  `noise` ([T] uniforms) / `n_dec` given: nothing
+        is drawn or read back here (graph capture)."""
         dev = target_mask.device
-        if seed is not None:
-            torch.manual_seed(seed)
-        n_dec = min(int(num_select), int((~target_mask[0]).sum().item()))
-        noise = torch.rand(target_mask.shape[1], device=dev).unsqueeze(0) * 1e-6
-        ids_shuffle = torch.argsort(target_mask.float() + noise, dim=1)
+        if noise is None:
+            if seed is not None:
+                torch.manual_seed(seed)
+            noise = torch.rand(target_mask.shape[1], device=dev)
+        if n_dec is None:
+            n_dec = min(int(num_select), int((~target_mask[0]).sum().item()))
+        ids_shuffle = torch.argsort(target_mask.float() + noise.unsqueeze(0) * 1e-6, dim=1)
         return ids_shuffle[:, :n_dec]
 
     def roar_step(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
                   seed=None, mod_pos: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
-                  return_logits: bool = False, forced_samples: Optional[torch.Tensor] = None):
+                  return_logits: bool = False, forced_samples: Optional[torch.Tensor] = None,
+                  static: Optional[dict] = None):
+        """static (graph capture): {"noise", "n_dec", "n_enc_cond", "n_enc_uncond", "ws"} - every count comes from the
+        schedule, every random number from a buffer filled before the replay: no host sync, no generator call."""
         if top_k and top_k > 0:
             raise NotImplementedError("top-k filtering is outside the hot-path scope (config 4 uses top-p)")
         eng = self.engine
+        st = static or {}
         d = mod_dict[target_mod]
         if mod_pos is None:
-            mod_pos = self.roar_order(d["target_mask"].to(eng.dev), num_select, seed)
+            mod_pos = self.roar_order(d["target_mask"].to(eng.dev), num_select, seed, noise=st.get("noise"), n_dec=st.get("n_dec"))
         mod_pos = mod_pos.to(eng.dev)
-        logits_cond = self._logits(mod_dict, target_mod, mod_pos)
+        logits_cond = self._logits(mod_dict, target_mod, mod_pos, n_enc=st.get("n_enc_cond"), ws=st.get("ws"))
+        if static is not None:
+            logits_cond = logits_cond.clone()          # the two passes share one workspace-independent output buffer each
         logits_uncond = None
         if guidance_scale != 1.0 and len(conditioning) > 0:
             uncond = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in mod_dict.items()}
             for mod in conditioning:
                 uncond = empty_img_modality(uncond, mod)
-            logits_uncond = self._logits(uncond, target_mod, mod_pos)
+            logits_uncond = self._logits(uncond, target_mod, mod_pos, n_enc=st.get("n_enc_uncond"), ws=st.get("ws"))
         B, M, V = logits_cond.shape
         if uniforms is None:
             uniforms = torch.rand(B * M, device=eng.dev)
@@ -182,3 +196,94 @@ class GenerationSampler:
                                       conditioning=info.get("cfg_cond_domains", []), guidance_scale=info.get("cfg_scale", 1.0),
                                       seed=None if seed is None else seed + step)
         return mod_dict
+
+    # ---- the whole schedule as ONE hipGraph (BASELINE config 4: "hipGraph-captured decode") ---------------------------
+    @torch.no_grad()
+    def generate_graphed(self, mod_dict, schedule, top_k=0.0, top_p=0.0, seed: int = 0):
+        """`generate` with every encoder-decoder pass, the device sampler and the token scatters of ALL schedule steps
+        replayed from one captured graph: one host call per clip batch, one host read (the initial mask counts) per call.
+
+        What makes that possible: with ROAR the kept-row counts of every pass follow from the schedule and the initial
+        number of unmasked inputs (conditional pass of step s: inputs + tokens decoded so far; unconditional: tokens
+        decoded so far, 0 on the first step), and the random ROAR order / sampling uniforms are drawn BEFORE the replay
+        with torch's generator seeded `seed + step` exactly as the eager path does - same tokens, bit for bit.
+        One graph per (batch, schedule, initial counts, top_p), kept in the engine's bounded graph cache."""
+        eng = self.engine
+        if top_k and top_k > 0:
+            raise NotImplementedError("top-k filtering is outside the hot-path scope (config 4 uses top-p)")
+        names = [m.name for m in eng.mods if m.name in mod_dict]
+        B = mod_dict[names[0]]["tensor"].shape[0]
+        flat = {n: {"tensor": mod_dict[n]["tensor"].reshape(B, -1).to(eng.dev, torch.int64),
+                    "input_mask": mod_dict[n]["input_mask"].reshape(B, -1).to(eng.dev, torch.bool),
+                    "target_mask": mod_dict[n]["target_mask"].reshape(B, -1).to(eng.dev, torch.bool)} for n in names}
+        # the one host read: unmasked inputs per sample and modality, open targets per modality (of sample 0, like :498-500)
+        cnt = torch.stack([torch.cat([(~flat[n]["input_mask"]).sum(1), (~flat[n]["target_mask"][0]).sum().reshape(1)]) for n in names]).cpu().numpy()
+        n_in = {n: cnt[i, :B].astype(np.int64) for i, n in enumerate(names)}            # [B] each
+        n_open = {n: int(cnt[i, B]) for i, n in enumerate(names)}
+        plan, dec_so_far = [], {n: 0 for n in names}
+        for info in schedule:
+            if info["scheme"].lower() != "roar":
+                raise NotImplementedError(f"scheme {info['scheme']} is outside the hot-path scope")
+            t = info["target_domain"]
+            n_dec = min(int(info["num_tokens"]), n_open[t] - dec_so_far[t])
+            cond = list(info.get("cfg_cond_domains", []))
+            guided = info.get("cfg_scale", 1.0) != 1.0 and len(cond) > 0
+            # rows kept by a pass = max over the batch of the unmasked inputs of all its modalities (:413-415)
+            total = int(sum(n_in[n] + dec_so_far[n] for n in names).max())
+            unc = [n for n in names if n not in cond]
+            total_u = int(sum(n_in[n] + dec_so_far[n] for n in unc).max()) if unc else 0
+            plan.append(dict(target=t, n_dec=n_dec, n_enc_cond=total, guided=guided, n_enc_uncond=total_u, info=info))
+            dec_so_far[t] += n_dec
+        key = ("generate", B, tuple(names), tuple((n, tuple(int(x) for x in n_in[n])) for n in names), tuple(sorted(n_open.items())), float(top_p),
+               tuple((p["target"], p["n_dec"], p["info"]["temperature"], p["info"].get("cfg_scale", 1.0),
+                      tuple(p["info"].get("cfg_cond_domains", []))) for p in plan))
+        graphs = eng.__dict__.setdefault("_graphs", {})
+        g = graphs.pop(key, None)
+        if g is None:
+            while len(graphs) >= eng.max_graphs:
+                graphs.pop(next(iter(graphs)))
+            if eng.weights_dirty:
+                eng.refresh_weights()
+            n_max = max(max(p["n_enc_cond"] for p in plan), 1)
+            m_max = max(p["n_dec"] for p in plan)
+            st = {"in": {n: {k: v.clone() for k, v in flat[n].items()} for n in names},
+                  "noise": [torch.zeros(flat[p["target"]]["target_mask"].shape[1], device=eng.dev) for p in plan],
+                  "uni": [torch.zeros(B * p["n_dec"], device=eng.dev) for p in plan],
+                  "ws": eng._alloc_infer(B, n_max, m_max, fresh=True), "out": None}
+
+            def run():
+                md = {n: {k: v.clone() for k, v in st["in"][n].items()} for n in names}
+                for i, p in enumerate(plan):
+                    info = p["info"]
+                    md = self.roar_step(md, p["target"], p["n_dec"], info["temperature"], 0.0, top_p,
+                                        conditioning=info.get("cfg_cond_domains", []), guidance_scale=info.get("cfg_scale", 1.0),
+                                        uniforms=st["uni"][i],
+                                        static=dict(noise=st["noise"][i], n_dec=p["n_dec"], n_enc_cond=p["n_enc_cond"],
+                                                    n_enc_uncond=p["n_enc_uncond"], ws=st["ws"]))
+                return md
+
+            side = torch.cuda.Stream(device=eng.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up outside the capture (lazy initialisations)
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = run()
+            g = (graph, st)
+        graphs[key] = g
+        graph, st = g
+        for n in names:
+            for k in ("tensor", "input_mask", "target_mask"):
+                st["in"][n][k].copy_(flat[n][k])
+        for i, p in enumerate(plan):                            # the eager path's draws, in its order (roar_order, then roar_step)
+            torch.manual_seed(seed + i)
+            st["noise"][i].copy_(torch.rand(st["noise"][i].shape[0], device=eng.dev))
+            st["uni"][i].copy_(torch.rand(st["uni"][i].shape[0], device=eng.dev))
+        graph.replay()
+        out = copy.deepcopy({n: dict(mod_dict[n]) for n in mod_dict if n not in names})
+        for n in names:
+            out[n] = {k: v.clone() for k, v in st["out"][n].items()}
+            for k, v in mod_dict[n].items():
+                out[n].setdefault(k, v)
+        return out

@@ -75,6 +75,25 @@ def clip_synth(key_ids, key_perm, k_in, k_tgt, n, vocab, ids, input_mask, target
                                   _p(input_mask), _p(target_mask), _p(dam), _stream()), "ego_clip_synth")
 
 
+def budget_dirichlet(keys, in_alphas, tgt_alphas, mix_weights, max_tokens, min_tokens, not_seq, n_in_range, n_tgt_range,
+                     k_in, k_tgt, max_tries=100):
+    """Dirichlet-mixture token budgets on the device.  in_alphas / tgt_alphas: [n_mix][n_mods]; k_in / k_tgt: int32 [n_mods, B]."""
+    _need_cuda(k_in)
+    d = L.BudgetDesc()
+    d.n_mix, d.n_mods = len(in_alphas), len(in_alphas[0])
+    for j in range(d.n_mix):
+        d.mix_weight[j] = float(mix_weights[j])
+        for i in range(d.n_mods):
+            d.in_alpha[j][i] = max(float(in_alphas[j][i]), 1e-9)
+            d.tgt_alpha[j][i] = max(float(tgt_alphas[j][i]), 1e-9)
+    for i in range(d.n_mods):
+        d.max_tokens[i], d.min_tokens[i], d.not_seq[i] = int(max_tokens[i]), int(min_tokens[i]), int(bool(not_seq[i]))
+    d.n_in_lo, d.n_in_hi = int(n_in_range[0]), int(n_in_range[1])
+    d.n_tgt_lo, d.n_tgt_hi = int(n_tgt_range[0]), int(n_tgt_range[1])
+    d.max_tries = int(max_tries)
+    check(L.load().ego_budget_dirichlet(C.byref(d), _p(keys), keys.numel(), _p(k_in), _p(k_tgt), _stream()), "ego_budget_dirichlet")
+
+
 def gemm_kernel_mode(nt256=1, tn256=1):
     """1 = tile family by shape (default), 0 = 128x128 kernels only, 2 = 256x256 wherever legal"""
     check(L.load().ego_gemm_kernel_mode(nt256, tn256), "ego_gemm_kernel_mode")
@@ -202,16 +221,29 @@ def embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D):
     check(L.load().ego_embed_fwd(C.byref(d), _stream()), "ego_embed_fwd")
 
 
-def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D):
+def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D, touched=None):
     d = L.EmbedBwdDesc()
     for i in range(len(dmods)):
         d.dtable[i] = None if dtables is None or dtables[i] is None else dtables[i].data_ptr()
         d.dmod[i] = dmods[i].data_ptr()
+        d.touched[i] = None if touched is None or touched[i] is None else touched[i].data_ptr()
     d.dbase = _p(dbase)
     d.dx, d.d2 = dx.data_ptr(), _p(d2)
     d.slot, d.tok = slot.data_ptr(), tok.data_ptr()
     d.rows, d.D, d.n_mods = rows, D, len(dmods)
     check(L.load().ego_embed_bwd(C.byref(d), _stream()), "ego_embed_bwd")
+
+
+def rows_compact(touched, cap, rows, count):
+    check(L.load().ego_rows_compact(_p(touched), touched.numel(), cap, _p(rows), _p(count), _stream()), "ego_rows_compact")
+
+
+def rows_gather(table, rows, count, cap, out):
+    check(L.load().ego_rows_gather(_p(table), _p(rows), _p(count), cap, table.shape[-1], _p(out), _stream()), "ego_rows_gather")
+
+
+def rows_scatter(table, rows, count, cap, src, add):
+    check(L.load().ego_rows_scatter(_p(table), _p(rows), _p(count), cap, table.shape[-1], _p(src), int(add), _stream()), "ego_rows_scatter")
 
 
 def loss_perm(seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base):

@@ -145,6 +145,22 @@ def build_state_dict(cfg: ModelCfg, seed: int = 0, posemb: bool = True) -> Dict[
     return sd
 
 
+def peak_logit_table(sd: Dict[str, torch.Tensor], mod: str, seed: int = 0, cap: float = 1.0e3) -> Dict[str, torch.Tensor]:
+    """Make the output head of `mod` PEAKED: row v of its (tied) logit table is multiplied by a Pareto(1) factor
+    1 / (1 - u_v) (capped).  Random-init tables give nearly flat logits over 64,000 tokens, where bf16 noise flips the
+    arg-max of ~10 % of the rows; with heavy-tailed row norms the top logit leads by far more than that noise, so
+    generation tests can demand token equality.  Deterministic (counter-based stream), applied in place."""
+    key = f"decoder_embeddings.{mod}.token_emb.weight"
+    w = sd[key]
+    u = uniform(f"peak.{mod}", (w.shape[0],), 0.0, 1.0, seed).double()
+    scale = torch.clamp(1.0 / (1.0 - u), max=cap).float()
+    w.mul_(scale[:, None])                    # to_logits.weight is the same tensor when tied
+    if sd.get(f"decoder_embeddings.{mod}.to_logits.weight") is not None and \
+            sd[f"decoder_embeddings.{mod}.to_logits.weight"].data_ptr() != w.data_ptr():
+        sd[f"decoder_embeddings.{mod}.to_logits.weight"].mul_(scale[:, None])
+    return sd
+
+
 # ----------------------------------------------------------------------------------------
 # synthetic clips (the `mod_dict` input contract, SURVEY.md section 8a row a0 / 8d)
 # ----------------------------------------------------------------------------------------
@@ -241,3 +257,84 @@ def dirichlet_budgets(cfg: ModelCfg, batch: int, n_in: int, n_tgt: int, seed: in
             k_tg = min(int(round(p_tg[j] * n_tgt)), m.max_tokens - k_in)
             res[m.name].append((k_in, k_tg))
     return res
+
+
+# The released mod4 mixture (cfgs/default/egom2p/alphas_mixture/main/mix_mod4_all2all_uni.yaml): four components with
+# alpha = 0.01 / 0.1 / 1 / 10 for every modality, uniform sampling weights.
+MOD4_MIXTURE_ALPHAS = (0.01, 0.1, 1.0, 10.0)
+
+
+def masking_budgets_host(cfg: ModelCfg, batch: int, n_in_range=(2048, 2048), n_tgt_range=(2048, 2048), seed: int = 0,
+                         alphas: Sequence[float] = MOD4_MIXTURE_ALPHAS, mix_weights: Optional[Sequence[float]] = None,
+                         min_tokens: int = 0, max_tries: int = 100):
+    """The reference's budget sampler restated on the host (`UnifiedMasking.input_token_budget` / `target_token_budget`,
+    egom2p/data/masking.py:181-234; mixture / token-count draws :530-541) with numpy's generator: floor of Dirichlet * N,
+    leftover tokens to the arg-max of further draws, clamp, redraw below min_tokens.  Returns int arrays [n_mods, batch]
+    (k_in, k_tgt) - the checker for the device sampler `ego_budget_dirichlet` (same law, independent random stream)."""
+    mods = cfg.mods
+    n = len(mods)
+    rng = np.random.default_rng([seed, 0xB0D6])
+    w = np.ones(len(alphas)) if mix_weights is None else np.asarray(mix_weights, dtype=np.float64)
+    w = w / w.sum()
+    max_tok = np.array([m.max_tokens for m in mods])
+    k_in = np.zeros((n, batch), dtype=np.int64)
+    k_tg = np.zeros((n, batch), dtype=np.int64)
+
+    def draw(alpha, total, cap):
+        a = np.full(n, max(alpha, 1e-9))
+        bud = np.zeros(n, dtype=np.int64)
+        for _ in range(max_tries):
+            bud = np.floor(rng.dirichlet(a) * total).astype(np.int64)
+            for _ in range(int(total - bud.sum())):
+                bud[int(np.argmax(rng.dirichlet(a)))] += 1
+            bud = np.minimum(bud, cap)
+            if (bud >= min_tokens).all():
+                break
+        return bud
+
+    for b in range(batch):
+        alpha = alphas[int(rng.choice(len(alphas), p=w))]
+        n_in = int(rng.integers(n_in_range[0], n_in_range[1] + 1))
+        n_tg = int(rng.integers(n_tgt_range[0], n_tgt_range[1] + 1))
+        ki = draw(alpha, n_in, max_tok)
+        kt = draw(alpha, n_tg, np.maximum(min_tokens, max_tok - ki))      # img / cam / gaze types: targets take what is left
+        k_in[:, b], k_tg[:, b] = ki, kt
+    return k_in, k_tg
+
+
+def masking_budgets_device(cfg: ModelCfg, batch: int, n_in_range=(2048, 2048), n_tgt_range=(2048, 2048), seed: int = 0,
+                           sample_offset: int = 0, alphas: Sequence[float] = MOD4_MIXTURE_ALPHAS,
+                           mix_weights: Optional[Sequence[float]] = None, min_tokens: int = 0, device: str = "cuda"):
+    """Token budgets of `batch` clips sampled ON THE DEVICE (ego_budget_dirichlet): int32 tensors [n_mods, batch]."""
+    from . import ops
+    mods = cfg.mods
+    keys = np.array([_key(f"clip{sample_offset + b}.budget", seed) for b in range(batch)], dtype=np.uint64)
+    kd = torch.from_numpy(keys.view(np.int64)).to(device)
+    k_in = torch.empty(len(mods), batch, dtype=torch.int32, device=device)
+    k_tg = torch.empty(len(mods), batch, dtype=torch.int32, device=device)
+    al = [[a] * len(mods) for a in alphas]
+    ops.budget_dirichlet(kd, al, al, [1.0] * len(alphas) if mix_weights is None else mix_weights, [m.max_tokens for m in mods],
+                         [min_tokens] * len(mods), [True] * len(mods), n_in_range, n_tgt_range, k_in, k_tg)
+    return k_in, k_tg
+
+
+def make_clip_batch_device_masked(cfg: ModelCfg, batch: int, n_in: int = 2048, n_tgt: int = 2048, seed: int = 0, sample_offset: int = 0,
+                                  device: str = "cuda") -> Dict[str, Dict[str, torch.Tensor]]:
+    """Synthetic clips whose budgets come from the reference's Dirichlet mixture, budgets AND masks made on the device:
+    nothing but the per-clip stream keys crosses the host-device boundary."""
+    from . import ops
+    k_in, k_tg = masking_budgets_device(cfg, batch, (n_in, n_in), (n_tgt, n_tgt), seed, sample_offset, device=device)
+    out: Dict[str, Dict[str, torch.Tensor]] = {}
+    for j, m in enumerate(cfg.mods):
+        n = m.max_tokens
+        keys = np.array([[_key(f"clip{sample_offset + b}.{m.name}.ids", seed), _key(f"clip{sample_offset + b}.{m.name}.perm", seed)]
+                         for b in range(batch)], dtype=np.uint64)
+        kd = torch.from_numpy(keys.view(np.int64)).to(device)
+        ids = torch.empty((batch, n), dtype=torch.int64, device=device)
+        in_mask = torch.empty((batch, n), dtype=torch.bool, device=device)
+        tg_mask = torch.empty((batch, n), dtype=torch.bool, device=device)
+        dam = torch.empty((batch, n), dtype=torch.int32, device=device)
+        ops.clip_synth(kd[:, 0].contiguous(), kd[:, 1].contiguous(), k_in[j], k_tg[j], n, m.vocab_size, ids, in_mask, tg_mask, dam)
+        shape = (batch,) + (m.grid if m.kind == "video" else (n,))
+        out[m.name] = {"tensor": ids.reshape(shape), "input_mask": in_mask, "target_mask": tg_mask, "decoder_attention_mask": dam}
+    return out

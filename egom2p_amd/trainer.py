@@ -11,18 +11,38 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from .dp import GradBucketReducer
+from .dp import GradBucketReducer, SparseTableExchange
 from .engine import Engine
 from .optim import FusedAdamW
 
 
 class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4, weight_decay: float = 0.05, clip_grad: Optional[float] = 1.0,
-                 process_group=None, world_size: int = 1, seed: int = 0, force_reducer: bool = False):
+                 process_group=None, world_size: int = 1, seed: int = 0, force_reducer: bool = False,
+                 clips_per_step: Optional[int] = None, sparse_tables: str = "auto"):
+        """clips_per_step (per rank) bounds the table rows one step can touch (clips x kept encoder tokens); with
+        sparse_tables = "auto" the encoder tables' gradients go through the row-list exchange when that moves fewer bytes
+        than the dense all-reduce ("on" / "off" force it)."""
         self.engine = engine
         self.opt = FusedAdamW(engine, lr=lr, weight_decay=weight_decay, world_size=world_size)
         self.clip = clip_grad
-        self.reducer = GradBucketReducer(engine.G, process_group, force=force_reducer) if (world_size > 1 or force_reducer) else None
+        self.sparse = None
+        skip = ()
+        if (world_size > 1 or force_reducer) and sparse_tables != "off" and clips_per_step is not None:
+            cap = clips_per_step * engine.N
+            V = max(m.vocab_size for m in engine.mods)
+            if sparse_tables == "on" or SparseTableExchange.worth_it(V, engine.D, cap, world_size):
+                # small tables (cam / gaze: 256 rows) stay on the dense path: only tables the rule favours are exchanged
+                picked = [(g, fl, m) for (g, fl), m in zip(engine.track_touched_table_rows(True), engine.mods)
+                          if sparse_tables == "on" or SparseTableExchange.worth_it(m.vocab_size, engine.D, cap, world_size)]
+                for i, m in enumerate(engine.mods):
+                    if all(m is not pm for _, _, pm in picked):
+                        engine.touched[i] = None
+                if picked:
+                    self.sparse = SparseTableExchange([(g, fl) for g, fl, _ in picked], cap, process_group)
+                    skip = tuple(f"enc_table.{m.name}" for _, _, m in picked)
+        self.reducer = (GradBucketReducer(engine.G, process_group, force=force_reducer, skip=skip)
+                        if (world_size > 1 or force_reducer) else None)
         self.rng = random.Random(seed)           # decoder modality shuffle (egom2p_model.py:312), per forward
         self.loss_sum = torch.zeros(1 + engine.n_mods, device=engine.dev)
 
@@ -40,6 +60,8 @@ class TrainStep:
             eng.backward(1.0 / k, bucket_done=self.reducer.on_bucket if (last and self.reducer is not None) else None)
         if self.reducer is not None:
             self.reducer.finish()
+        if self.sparse is not None:
+            self.sparse.exchange()
         if lr is not None:
             for g in self.opt.param_groups:
                 g["lr"] = lr * g["lr_scale"]

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--bench", type=int, default=0, help="time this many generate() calls after one warm-up")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels one by one instead of replaying hipGraphs")
+    ap.add_argument("--graph", choices=["schedule", "pass"], default="schedule",
+                    help="schedule: all 6 passes + samplers + scatters of a clip batch are ONE captured graph; pass: one graph per pass")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     device = "cuda"
@@ -47,7 +49,13 @@ def main():
         # weights_only=True: nothing from the file is executed
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu", weights_only=True)["model"])
     model.eval()
-    sampler = GenerationSampler(model, use_graphs=not args.no_graphs)
+    sampler = GenerationSampler(model, use_graphs=(not args.no_graphs) and args.graph == "pass")
+    whole = (not args.no_graphs) and args.graph == "schedule"
+
+    def generate(sample):
+        if whole:
+            return sampler.generate_graphed(sample, schedule, seed=0, top_p=top_p, top_k=top_k)
+        return sampler.generate(sample, schedule, verbose=False, seed=0, top_p=top_p, top_k=top_k)
 
     cond_domains, target_domains, tokens_per_target = ["tok_rgb"], ["tok_depth"], [5120]
     schedule = build_chained_generation_schedules(
@@ -67,19 +75,19 @@ def main():
     for c in cond_domains:
         sample = init_full_input_modality(sample, MODALITY_INFO, c, device)
 
-    out = sampler.generate(sample, schedule, verbose=False, seed=0, top_p=top_p, top_k=top_k)
+    out = generate(sample)
     torch.cuda.synchronize()
     if args.out:
         np.savez_compressed(args.out, tok_depth=out["tok_depth"]["tensor"].cpu().numpy().astype(np.int32))
     if args.bench > 0:
         t0 = time.perf_counter()
         for _ in range(args.bench):
-            sampler.generate(sample, schedule, verbose=False, seed=0, top_p=top_p, top_k=top_k)
+            generate(sample)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.bench
         # forward FLOPs of the 6 passes: dense attention, N = 5120/6827/8534 (cond), 0/1707/3414 (uncond)
         print(json.dumps({"metric": "rgb2depth generation (ROAR 3 steps, CFG 2.0, top-p 0.8)", "model": args.model,
-                          "batch": args.batch, "s_per_clip": dt / args.batch, "clips_per_s": args.batch / dt,
+                          "graph": "none" if args.no_graphs else args.graph, "batch": args.batch, "s_per_clip": dt / args.batch, "clips_per_s": args.batch / dt,
                           "passes_per_clip": 6, "ms_per_pass": dt / 6 * 1e3}))
     print("done: depth tokens", tuple(out["tok_depth"]["tensor"].shape))
 

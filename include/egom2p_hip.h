@@ -84,8 +84,19 @@ typedef struct {
     const float* dx; const float* d2;
     const int* slot; const int* tok;
     long rows; int D, n_mods;
+    unsigned char* touched[EGO_MAX_MODS];   /* optional uint8 [V] per table: set to 1 for every row that got a gradient */
 } ego_embed_bwd_desc;
 int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream);
+
+/* Row lists for the sparse data-parallel exchange of an embedding table's gradient (replaces, for few clips per step,
+ * the dense all-reduce DDP performs on the 64000 x 768 tables, run_training_egom2p.py:514; encoder_embeddings.py:200,291).
+ * ego_rows_compact: touched[V] -> rows[cap] ascending (-1 padded), *count = number of rows (bit 30 set: more than cap
+ * rows were touched, the list is truncated); clears the flags.  ego_rows_gather: out[i] = table[rows[i]] (zeros past
+ * count).  ego_rows_scatter: table[rows[i]] = (add ? table[rows[i]] : 0) + src[i] for i < *count (src NULL: zeros). */
+int ego_rows_compact(void* touched, int V, int cap, int* rows, int* count, hipStream_t stream);
+int ego_rows_gather(const float* table, const int* rows, const int* count, int cap, int D, float* out, hipStream_t stream);
+int ego_rows_scatter(float* table, const int* rows, const int* count, int cap, int D, const float* src, int add,
+                     hipStream_t stream);
 
 /* Row order of `y[decoder_mod_mask == id]` for every modality (egom2p_model.py:633): perm[row] = row
  * in the modality-grouped order (-1 for padding), targets gathered alongside, (offset,count) per
@@ -166,6 +177,24 @@ int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, 
  * egom2p_amd/synth.py:make_clip_batch.  n <= 8192. */
 int ego_clip_synth(const void* key_ids, const void* key_perm, const int* k_in, const int* k_tgt, int B, int n, int vocab,
                    long* ids, void* input_mask, void* target_mask, int* dam, hipStream_t stream);
+
+/* Token budgets per clip and modality, the reference's Dirichlet-mixture sampler (`UnifiedMasking.input_token_budget` /
+ * `target_token_budget`, egom2p/data/masking.py:181-234, mixture / token-count draws :530-541) on the device: floor of
+ * Dirichlet(alpha) * N, leftover tokens to the arg-max of further draws, clamp to max_tokens (targets: to what the inputs
+ * left), redraw below min_tokens.  clip_keys: one 64-bit stream key per clip.  k_in / k_tgt: int32 [n_mods, B] - the
+ * per-modality rows feed ego_clip_synth directly.  alphas are clamped by the caller (> 0; the reference clamps at 1e-9). */
+#define EGO_MAX_MIX 8
+typedef struct {
+    int n_mods, n_mix;
+    float in_alpha[EGO_MAX_MIX][EGO_MAX_MODS];     /* [mixture component][modality] */
+    float tgt_alpha[EGO_MAX_MIX][EGO_MAX_MODS];
+    float mix_weight[EGO_MAX_MIX];                 /* sampling_weights of the mixture */
+    int max_tokens[EGO_MAX_MODS], min_tokens[EGO_MAX_MODS];
+    int not_seq[EGO_MAX_MODS];                     /* 1: img / cam / gaze type (targets cannot reuse input positions) */
+    int n_in_lo, n_in_hi, n_tgt_lo, n_tgt_hi;      /* input_tokens_range / target_tokens_range, inclusive */
+    int max_tries;
+} ego_budget_desc;
+int ego_budget_dirichlet(const ego_budget_desc* d, const void* clip_keys, int B, int* k_in, int* k_tgt, hipStream_t stream);
 
 /* ---- loss head ------------------------------------------------------------------------------- */
 

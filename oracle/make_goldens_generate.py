@@ -7,7 +7,7 @@ come from the counter-based generator.  Per schedule step the fixture holds the 
 statistics of the conditional / unconditional logits, and the tokens the reference sampled (teacher forcing
 for the next step).
 
-    python oracle/make_goldens_generate.py
+    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768]
 """
 from __future__ import annotations
 
@@ -46,12 +46,19 @@ def main():
     sys.modules["egom2p.utils"].merge_span_masking = tt.merge_span_masking
     G = _load("egom2p.models.generate", "egom2p/models/generate.py")
 
-    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
-    seed = 21
+    which = sys.argv[1] if len(sys.argv) > 1 else "gen_rgb2depth"
+    # gen_rgb2depth: D = 384 plumbing case.  gen_rgb2depth_b768: ego-b width (D = 768, 12 heads) with a PEAKED depth head
+    # (synth.peak_logit_table), so that the sampled tokens themselves can be compared
+    cfg_name, seed, peaked = {"gen_rgb2depth": ("ego_gen_384_2e_2d", 21, False),
+                              "gen_rgb2depth_b768": ("ego_b_gen_2e_2d", 22, True)}[which]
+    cfg = MODEL_CFGS[cfg_name]
     torch.set_num_threads(8)
     torch.set_grad_enabled(False)
     net = MG.build_reference_model(cfg, enc, dec, model)
-    net.load_state_dict(synth.build_state_dict(cfg, seed), strict=True)
+    sd = synth.build_state_dict(cfg, seed)
+    if peaked:
+        synth.peak_logit_table(sd, "tok_depth", seed)
+    net.load_state_dict(sd, strict=True)
     net.eval()
     sampler = G.GenerationSampler(net)
     info = net.modality_info
@@ -70,7 +77,7 @@ def main():
     top_p, top_k, gseed = 0.8, 0.0, 0
 
     gold = {"rgb_ids": ids.astype(np.int32), "n_steps": np.array(len(schedule)),
-            "meta": np.array(repr(dict(cfg="ego_gen_384_2e_2d", seed=seed, top_p=top_p, gen_seed=gseed)))}
+            "meta": np.array(repr(dict(cfg=cfg_name, seed=seed, top_p=top_p, gen_seed=gseed, peaked=peaked)))}
     mod_dict = copy.deepcopy(sample)
     for step, sinfo in enumerate(schedule):
         target, num_select, temp, cfg_scale = sinfo["target_domain"], sinfo["num_tokens"], sinfo["temperature"], sinfo["cfg_scale"]
@@ -102,7 +109,7 @@ def main():
     gold["final_tokens"] = mod_dict["tok_depth"]["tensor"].numpy().astype(np.int32)
     # schedule check values
     gold["schedule_tokens"] = np.array([s["num_tokens"] for s in schedule])
-    path = os.path.join(ROOT, "tests", "golden", "gen_rgb2depth.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"{which}.npz")
     np.savez_compressed(path, **gold)
     print(f"[goldens] -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 

@@ -85,3 +85,60 @@ def test_reducer_is_noop_single_process():
     red.on_bucket("y", 0, 5)
     red.finish()
     assert red.launched == [] and red.last_launched == []
+
+
+def _sparse_worker(rank, world, port, ret):
+    from egom2p_amd.dp import SparseTableExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    V, D, cap = 3000, 48, 256
+    gen = torch.Generator().manual_seed(100 + rank)
+    tables = []
+    for t in range(2):                                       # two tables, overlapping and rank-private rows
+        g = torch.zeros(V, D)
+        touched = torch.zeros(V, dtype=torch.uint8)
+        rows = torch.randperm(V, generator=gen)[:150 + 30 * t]
+        rows = torch.cat([rows, torch.tensor([7, 11, 13 + t])])          # rows every rank touches
+        for _ in range(2):                                   # two micro-batches accumulate into the same rows
+            g[rows] += torch.randn(rows.numel(), D, generator=gen)
+            touched[rows] = 1
+        tables.append((g, touched))
+    dense = [g.clone() for g, _ in tables]
+    for d in dense:
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+    ex = SparseTableExchange(tables, cap_rows=cap)
+    assert ex.world == 2
+    ex.exchange()
+    assert not ex.overflowed()
+    worst = 0.0
+    for (g, touched), d in zip(tables, dense):
+        assert int(touched.sum()) == 0                       # flags consumed
+        worst = max(worst, float((g - d).abs().max()))
+    # the result is bitwise the same on both ranks (one fixed summation order)
+    chk = torch.cat([g.reshape(-1) for g, _ in tables]).double().sum().reshape(1)
+    both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both, chk)
+    # a cap that is too small is reported, not silently truncated
+    tiny = SparseTableExchange([(torch.zeros(V, D), torch.ones(V, dtype=torch.uint8))], cap_rows=16)
+    tiny.exchange()
+    if rank == 0:
+        ret["worst"] = worst
+        ret["same"] = float(both[0]) == float(both[1])
+        ret["overflow_seen"] = tiny.overflowed()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_table_exchange_equals_dense_allreduce():
+    """(row id, row) lists instead of the dense all-reduce of an embedding table."""
+    from egom2p_amd.dp import SparseTableExchange
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sparse_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["worst"] < 1e-6 and ret["same"] and ret["overflow_seen"], dict(ret)
+    # the byte rule: 4 clips x 2048 kept rows per GPU at 8 GPUs favours the lists, 256 clips per GPU the dense all-reduce
+    assert SparseTableExchange.worth_it(64000, 768, 4 * 2048, 8)
+    assert not SparseTableExchange.worth_it(64000, 768, 256 * 2048, 8)
+    assert not SparseTableExchange.worth_it(256, 768, 4 * 2048, 8)          # cam / gaze tables stay dense

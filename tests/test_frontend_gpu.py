@@ -150,3 +150,87 @@ def test_clip_synth_on_device_is_bit_identical_to_host():
         for m in cfg.mods:
             for k in ("tensor", "input_mask", "target_mask", "decoder_attention_mask"):
                 assert torch.equal(dev[m.name][k].cpu(), host[m.name][k]), (m.name, k)
+
+
+def test_device_budget_sampler_follows_the_reference_mixture():
+    """the Dirichlet-mixture token budgets of `UnifiedMasking` (masking.py:181-234, :530-541)
+    sampled on the device.  Checked against the host restatement of the same algorithm (independent random stream):
+    per-sample invariants exactly, distribution by moments and by the share of near-one-hot draws (alpha 0.01 / 0.1
+    components put almost every token on one modality until it hits its cap)."""
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    B, N = 20000, 2048
+    k_in, k_tg = synth.masking_budgets_device(cfg, B, (N, N), (N, N), seed=5)
+    torch.cuda.synchronize()
+    di, dt = k_in.cpu().numpy().astype(np.int64), k_tg.cpu().numpy().astype(np.int64)
+    hi, ht = synth.masking_budgets_host(cfg, B, (N, N), (N, N), seed=5)
+    cap = np.array([m.max_tokens for m in cfg.mods])[:, None]
+    for a, t in ((di, dt), (hi, ht)):
+        assert (a >= 0).all() and (t >= 0).all() and (a <= cap).all() and (a + t <= cap).all()
+        assert (a.sum(0) <= N).all() and (t.sum(0) <= N).all()
+        # the sum is exact unless a clamp took tokens away (then some modality sits at its cap)
+        short = a.sum(0) < N
+        assert ((a == cap).any(0) | ~short).all()
+    # moments per modality (rgb / depth share the law, so do cam / gaze): 20,000 samples each side
+    for arr_d, arr_h in ((di, hi), (dt, ht)):
+        md, mh = arr_d.mean(1), arr_h.mean(1)
+        sd_, sh = arr_d.std(1), arr_h.std(1)
+        assert np.all(np.abs(md - mh) < 0.03 * mh + 0.5), (md, mh)
+        assert np.all(np.abs(sd_ - sh) < 0.05 * sh + 0.5), (sd_, sh)
+        # share of clips whose budget is (almost) all on one modality
+        one_d = ((arr_d.max(0) >= 0.95 * arr_d.sum(0).clip(min=1))).mean()
+        one_h = ((arr_h.max(0) >= 0.95 * arr_h.sum(0).clip(min=1))).mean()
+        assert abs(one_d - one_h) < 0.02, (one_d, one_h)
+    # budgets -> masks -> compaction on the device: a clip batch with nothing but stream keys from the host
+    md = synth.make_clip_batch_device_masked(cfg, 6, N, N, seed=9)
+    for j, m in enumerate(cfg.mods):
+        kin = (~md[m.name]["input_mask"]).sum(1).cpu().numpy()
+        ktg = (~md[m.name]["target_mask"]).sum(1).cpu().numpy()
+        overlap = (~md[m.name]["input_mask"] & ~md[m.name]["target_mask"]).sum().item()
+        assert overlap == 0 and (kin + ktg <= m.max_tokens).all()
+        assert (md[m.name]["decoder_attention_mask"].sum(1).cpu().numpy() == ktg).all()
+    eng_out = _run_compact(cfg, {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in md.items()}, cfg.mods, N, True)
+    assert eng_out["err"].item() == 0
+
+
+def test_row_list_kernels_and_sparse_exchange_single_rank():
+    """The ego_rows_* kernels under dp.SparseTableExchange on the GPU: a one-rank exchange must
+    leave the table as it was, the row list is the ascending set of flagged rows, and the embedding backward sets the
+    flags of exactly the token rows it adds to."""
+    from egom2p_amd.dp import SparseTableExchange
+    V, D, cap = 64000, 768, 5000
+    g = torch.zeros(V, D, device=DEV)
+    touched = torch.zeros(V, dtype=torch.uint8, device=DEV)
+    rows = torch.randperm(V, device=DEV)[:3000]
+    g[rows] = torch.randn(3000, D, device=DEV)
+    touched[rows] = 1
+    ref = g.clone()
+    ex = SparseTableExchange([(g, touched)], cap_rows=cap)
+    ex.exchange()
+    torch.cuda.synchronize()
+    t = ex.tables[0]
+    n = int(t["count"].item())
+    assert n == 3000 and torch.equal(t["rows"][:n].long(), torch.sort(rows).values) and (t["rows"][n:] == -1).all()
+    assert torch.equal(g, ref) and int(touched.sum()) == 0
+    assert torch.equal(t["send"][:n], ref[t["rows"][:n].long()]) and float(t["send"][n:].abs().max()) == 0.0
+    # overflow is reported
+    touched[:] = 1
+    small = SparseTableExchange([(g, touched)], cap_rows=100)
+    small.exchange()
+    assert small.overflowed()
+    # flags from the embedding backward
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    from egom2p_amd.engine import Engine
+    eng = Engine(cfg, "cuda:0", max_batch=2, n_enc=256, n_dec=256)
+    eng.init_random(1)
+    tabs = eng.track_touched_table_rows(True)
+    md = synth.make_clip_batch(cfg, 2, None, seed=4)
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    eng.forward(mdg)
+    eng.zero_grad()
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    for (gt, fl), m in zip(tabs, cfg.mods):
+        nz = (gt.abs().sum(1) > 0)
+        assert torch.equal(fl.bool() | ~nz, torch.ones_like(nz))              # every row with a gradient is flagged
+        slot_rows = eng.ce["tok"][:2][eng.ce["slot"][:2] == cfg.mods.index(m)].long().unique()
+        assert torch.equal(torch.nonzero(fl).flatten(), slot_rows)            # and exactly the kept token ids are

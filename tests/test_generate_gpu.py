@@ -81,11 +81,19 @@ def test_schedule_matches_reference():
     assert all(s["cfg_cond_domains"] == ["tok_rgb"] and s["cfg_scale"] == 2.0 and s["temperature"] == 0.01 for s in sch)
 
 
-def test_roar_cfg_generation_matches_reference():
-    g, meta = load_golden("gen_rgb2depth")
+@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768"])
+def test_roar_cfg_generation_matches_reference(fixture):
+    """gen_rgb2depth: D = 384 with a random-init (flat) head - near-ties decide most tokens, so the bars are on the logits.
+    gen_rgb2depth_b768: ego-b width (D = 768, 12 heads, N up to 8534) with a PEAKED depth head (synth.peak_logit_table):
+    arg-max and sampled tokens must agree with the reference's on >= 99 % of the rows."""
+    g, meta = load_golden(fixture)
     cfg = MODEL_CFGS[meta["cfg"]]
+    peaked = bool(meta.get("peaked", False))
     eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=64, n_dec=64)
-    eng.load_state_dict(synth.build_state_dict(cfg, meta["seed"]))
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    if peaked:
+        synth.peak_logit_table(sd, "tok_depth", meta["seed"])
+    eng.load_state_dict(sd)
     sampler = GenerationSampler(eng)
     sample = {"tok_rgb": {"tensor": torch.from_numpy(g["rgb_ids"].astype(np.int64)).to(DEV)}}
     sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 1, 5120, DEV)
@@ -102,9 +110,10 @@ def test_roar_cfg_generation_matches_reference():
             lg = lg[0].float()
             assert rel_l2(lg[:6, :48].cpu().numpy(), g[f"s{step}.{nm}.head"]) < 3e-2, (step, nm)
             assert rel_l2(lg.norm(dim=-1).cpu().numpy(), g[f"s{step}.{nm}.rownorm"]) < 1e-2, (step, nm)
-            assert np.abs(torch.logsumexp(lg, -1).cpu().numpy() - g[f"s{step}.{nm}.lse"]).max() < 5e-2, (step, nm)
+            lse_scale = max(1.0, float(np.abs(g[f"s{step}.{nm}.max"]).max()))          # peaked heads have logits in the hundreds
+            assert np.abs(torch.logsumexp(lg, -1).cpu().numpy() - g[f"s{step}.{nm}.lse"]).max() < 5e-2 * lse_scale, (step, nm)
             am = (lg.argmax(-1).cpu().numpy() == g[f"s{step}.{nm}.argmax"]).mean()
-            assert am > 0.9, (step, nm, am)
+            assert am > (0.99 if peaked else 0.9), (step, nm, am)
         # the sampler (temperature 0.01 -> nearly greedy on the CFG-mixed logits) agrees with the reference's draws
         mine = info["samples"][0].cpu().numpy()
         agree_total += (mine == g[f"s{step}.samples"][0]).sum()
@@ -113,9 +122,11 @@ def test_roar_cfg_generation_matches_reference():
         mixed = info["logits_uncond"][0].float() + (info["logits_cond"][0].float() - info["logits_uncond"][0].float()) * float(cfg_scale)
         ref_tok = torch.from_numpy(g[f"s{step}.samples"][0].astype(np.int64)).to(DEV)
         gap = (mixed.gather(1, torch.from_numpy(mine.astype(np.int64)).to(DEV)[:, None]) - mixed.gather(1, ref_tok[:, None])).abs()
-        assert gap.max().item() < 0.35, (step, gap.max().item())
-    # random-init weights give nearly flat logits: bf16 noise flips near-ties, the gap bound above is the real bar
-    assert agree_total / n_total > 0.7, agree_total / n_total
+        # a differing token is a proven near-tie: its mixed logit is within bf16 noise of the reference token's
+        assert gap.max().item() < 0.35 * max(1.0, 0.02 * float(mixed.abs().max())), (step, gap.max().item())
+    # random-init weights give nearly flat logits: bf16 noise flips near-ties there (the gap bound above is the real bar);
+    # with the peaked head the sampled tokens themselves agree
+    assert agree_total / n_total > (0.99 if peaked else 0.7), agree_total / n_total
     assert np.array_equal(md["tok_depth"]["tensor"].cpu().numpy().astype(np.int32), g["final_tokens"])   # teacher-forced state
     assert (~md["tok_depth"]["input_mask"]).all() and md["tok_depth"]["target_mask"].all()
 
@@ -161,3 +172,25 @@ def test_hipgraph_replay_is_bitwise_identical():
     a = GenerationSampler(eng, use_graphs=False).generate(sample, sch, top_p=0.8, seed=3)["tok_depth"]["tensor"]
     b = GenerationSampler(eng, use_graphs=True).generate(sample, sch, top_p=0.8, seed=3)["tok_depth"]["tensor"]
     assert torch.equal(a, b)
+
+
+def test_whole_schedule_graph_matches_eager_generation():
+    """BASELINE config 4 "hipGraph-captured decode": the 6 encoder-decoder passes, 3 sampler launches and the token
+    scatters of a schedule replayed from ONE captured graph produce the tokens of the eager path, bit for bit, also
+    when the graph is replayed on new clips and seeds."""
+    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=2, n_enc=64, n_dec=64)
+    eng.init_random(6)
+    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+                                             [2.0], ["constant"], cfg_grow_conditioning=True)
+    eager, graphed = GenerationSampler(eng, use_graphs=False), GenerationSampler(eng)
+    for trial in range(3):
+        sample = {"tok_rgb": {"tensor": synth.randint(f"ws{trial}.rgb", (2, 5, 32, 32), 64000, seed=trial).to(DEV)}}
+        sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 2, 5120, DEV)
+        sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+        a = eager.generate(sample, sch, top_p=0.8, seed=10 + trial)
+        b = graphed.generate_graphed(sample, sch, top_p=0.8, seed=10 + trial)
+        assert torch.equal(a["tok_depth"]["tensor"], b["tok_depth"]["tensor"]), trial
+        assert torch.equal(a["tok_depth"]["input_mask"], b["tok_depth"]["input_mask"])
+        assert b["tok_depth"]["target_mask"].all() and sample["tok_depth"]["input_mask"].all()
+    assert sum(1 for k in eng._graphs if k[0] == "generate") == 1          # one graph served all three clips
