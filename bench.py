@@ -93,6 +93,7 @@ def main():
                     help="quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; full: SURVEY 8(d) protocol (~15 min)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
     args = ap.parse_args()
 
     from egom2p_amd import synth
@@ -119,7 +120,7 @@ def main():
     mb = min(args.micro_batch, args.clips_per_gpu)
     n_mb = args.clips_per_gpu // mb
     clips = n_mb * mb
-    eng = Engine(cfg, dev, max_batch=mb, n_enc=n_enc, n_dec=n_dec)
+    eng = Engine(cfg, dev, max_batch=mb, n_enc=n_enc, n_dec=n_dec, fp8_forward=args.fp8)
     eng.init_random(seed=0)                      # same weights on every rank (DDP broadcast semantics)
     budgets = synth.CANONICAL_BUDGETS
     pool = 2                                     # distinct micro-batches per rank, cycled (inputs stay in HBM)
@@ -164,7 +165,7 @@ def main():
                    f"multimodal tokens/sec ({args.model}, 10300-tok clips), training fwd+bwd+allreduce+AdamW"),
         "value": value, "unit": "clip-positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16+fp8fwd" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} mod4, synthetic 10300-position clips (1009+1009 rgb, 1009+1009 depth, 15+15 cam, "
                                f"15+15 gaze kept -> N=M=2048), bf16 MFMA GEMM/attention, fp32 residual/LN/CE/AdamW",
                    "clips_per_gpu_per_step": clips, "micro_batch": mb, "global_batch": clips * world, "parallelism": f"dp{world}"},

@@ -62,10 +62,13 @@ _SIGS = {
     "ego_rows_gather": [vp, vp, vp, i32, i32, vp, vp],
     "ego_rows_scatter": [vp, vp, vp, i32, i32, vp, i32, vp],
     "ego_loss_perm": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
-    "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i64, vp, vp],
     "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
+    "ego_quant_fp8_rows": [vp, i64, i64, i32, vp, i64, vp, vp],
+    "ego_gemm_nt_fp8": [vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp],
+    "ego_gemm_nt_swiglu_fwd_fp8": [vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp],
     "ego_gemm_tn_plan": [i32, i32, i32, i64, i64, i64, i32],
     "ego_attn_fwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64,
                          i32, i32, i32, i32, f32, vp],

@@ -37,6 +37,7 @@ struct NTArgs {
     int M, N, K, epi;
     const bf16_t* X; long ldx;      // EPI_SWIGLU_BWD: the saved SwiGLU pre-activations ab [M, 2N]
     bf16_t* H; long ldh;            // EPI_SWIGLU_FWD: the gate output h [M, N]
+    const float* sa; const float* sb;   // fp8 operands: per-row scales of A [M] and of B [N rows] (C = sa[m] * sb[n] * acc)
 };
 constexpr int EPI_SWIGLU_FWD = 101;   // internal: C = ab [M, 2N] and H = bf16(bf16(silu(a)) * b) [M, N] from one 256 x (128 a + 128 b) tile
 constexpr int EPI_SWIGLU_BWD = 100;   // internal: C(bf16)[M, 2N] = SwiGLU backward of (acc rounded to bf16) against X
@@ -260,8 +261,22 @@ __device__ __forceinline__ void bar_pinned() {
 constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
 constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
 
-template <int EK>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward, 3 fused SwiGLU forward (separate register allocations)
+// FP8: operands are OCP e4m3 bytes with one fp32 scale per row (A) / per output channel (B).  A 128-byte LDS row then holds
+// 128 k-values instead of 64, everything about the staging (LDS-DMA pieces, swizzle, rings, K-tiles of 128 BYTES) is
+// unchanged, and one v_mfma_scale_f32_16x16x128_f8f6f4 (block scales fixed to 1.0: E8M0 127) replaces the two 16x16x32
+// bf16 MFMAs of a K-tile at the same cycles - twice the contraction per tile.  Lane l supplies row l & 15, k-bytes
+// 32 (l >> 4) .. +31 of either operand (probed with exact e4m3 data: tools/probes/mfma_fp8_probe.cpp); the accumulator
+// layout is the bf16 one, and the row / column scales are applied when the epilogue reads the accumulators.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int EK, bool FP8 = false>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward, 3 fused SwiGLU forward (separate register allocations)
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
+    constexpr int ESZ = FP8 ? 1 : 2;                           // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,25 +292,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     // M may come from the device (row range of one modality): spread the tiles that really exist over the XCDs
     const int ntiles = ((M + 255) / 256) * tiles_n;
     if ((int)blockIdx.x >= ntiles) return;
-    const int nt = p.K / BK;
+    const int nt = p.K * ESZ / 128;                            // K-tiles of 128 bytes
     const int G = gridDim.x;
 
     // A: one descriptor per 256-row tile (based at the tile's first row, sized to its valid rows), so the 32-bit buffer
     // offsets never see more than 256 rows - activations / logit gradients larger than 4 GiB are fine
     auto a_rsrc = [&](int row0) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (moff + row0) * p.lda), 0,
-                                                 (int)(unsigned)((long)(min(256, M - row0) - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (moff + row0) * p.lda * ESZ), 0,
+                                                 (int)(unsigned)((long)(min(256, M - row0) - 1) * p.lda * ESZ + (long)p.K * ESZ), 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.B, 0, (int)(unsigned)((long)((EK == 3 ? 2 * p.N : p.N) - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
+        (void*)p.B, 0, (int)(unsigned)((long)((EK == 3 ? 2 * p.N : p.N) - 1) * p.ldb * ESZ + (long)p.K * ESZ), 0x00020000);
     // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
-    unsigned a_off[4], b_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
-        a_off[j] = (unsigned)(r * (int)p.lda * 2 + c);
-        b_off[j] = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * 2 + c);
+    // (piece j of a wave starts 8 rows after piece j - 1: one lane offset per operand, the rest goes into the scalar offset)
+    unsigned a_off0, b_off0;
+    {
+        const int r = 8 * (wave * 4) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
+        a_off0 = (unsigned)(r * (int)p.lda * ESZ + c);
+        b_off0 = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * ESZ + c);
     }
+    const unsigned a_step = (unsigned)(8 * (int)p.lda * ESZ), b_step = (unsigned)(8 * (int)p.ldb * ESZ);
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
         row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * tile_w;
@@ -315,24 +331,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             if (idA < ntiles) { tile_origin(idA, rA, cA_unused); ars = a_rsrc(rA); } else moreA = false;
         }
     };
-    auto cursorB = [&]() { b_so = (unsigned)cB * (unsigned)(p.ldb * 2) + (unsigned)(ktB * BK * 2); };
+    auto cursorB = [&]() { b_so = (unsigned)cB * (unsigned)(p.ldb * ESZ) + (unsigned)(ktB * BK * 2); };
     auto advanceB = [&]() {
         slotB ^= 1;
         if (++ktB == nt) { ktB = 0; idB += G; if (idB < ntiles) tile_origin(idB, rB_unused, cB); else moreB = false; }
     };
     auto dmaA = [&](int slot, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (wave * 4 + j) * 1024),
-                                                 16, a_off[j], (int)a_so, 0, 0);
+                                                 16, a_off0, (int)(a_so + j * a_step), 0, 0);
     };
     auto dmaB = [&](int slot, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
-                                                 16, b_off[j], (int)b_so, 0, 0);
+                                                 16, b_off0, (int)(b_so + j * b_step), 0, 0);
     };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
     int foff[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks)      // fp8: the two 16-byte halves of the lane's 32 k-bytes; bf16: the lane's chunk of k-step ks
+        foff[ks] = (lane & 15) * 128 + (((FP8 ? 2 * (lane >> 4) + ks : ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
     const int a_base = grp * 128 * 128, b_base = wc * 64 * 128;
 
     int id = blockIdx.x, row0, col0;
@@ -366,10 +383,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         bq[ni][ks] = *(const bf16x8*)(sb + b_base + ((QN) * 2 + ni) * 2048 + foff[ks]);
 #define COMPUTE(QM, QN)                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                         \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)      \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                   \
-            acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
-                bq[ni][ks], af[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                       \
+    if constexpr (FP8) {                                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)  \
+            acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(          \
+                cat_frag(bq[ni][0], bq[ni][1]), cat_frag(af[mi][0], af[mi][1]),                            \
+                acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0, 127, 0, 127);                                  \
+    } else {                                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)  \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                               \
+                acc[(QM) * 4 + mi][(QN) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(               \
+                    bq[ni][ks], af[mi][ks], acc[(QM) * 4 + mi][(QN) * 2 + ni], 0, 0, 0);                   \
+    }                                                                                                      \
     __builtin_amdgcn_s_setprio(0);
 
     while (true) {
@@ -432,6 +456,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         // in the B slot, [row][512 B], 16-byte chunk c of row r at chunk c ^ (r & 15): whole-row coalesced stores.
         char* ea = smem + (curA == 0 ? 2 : curA - 1) * RA_BYTES;
         char* ebb = smem + (3 + (curB ^ 1)) * RA_BYTES;
+        if constexpr (FP8) {
+            // C = sa[m] * sb[n] * acc: this lane's 8 rows (i) and 4 x 4 columns (j) of the tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tc = wc * 64 + j * 16 + (lane >> 4) * 4;                         // first of 4 tile columns
+                const int bn = EK == 3 ? (tc < 128 ? col0 + tc : p.N + col0 + tc - 128) : min(col0 + tc, p.N - 4);
+                const f32x4 cb = *(const f32x4*)(p.sb + bn);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ra = p.sa[moff + min(row0 + grp * 128 + i * 16 + (lane & 15), M - 1)];    // (L1-resident re-read)
+                    acc[i][j] = acc[i][j] * (cb * ra);
+                }
+                __builtin_amdgcn_sched_barrier(0);                                         // keep the live set at one column group
+            }
+        }
         if constexpr (EK == 0) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -1055,6 +1094,9 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     g_attr_done = true;
 }
@@ -1084,7 +1126,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
-    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0, nullptr, 0};
+    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0, nullptr, 0, nullptr, nullptr};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     // The persistent 256x256 kernel runs one workgroup per CU.  Measured on MI355X (tools/gemm_bench.py, EGO_GEMM_NT256=2
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
@@ -1112,9 +1154,42 @@ extern "C" int ego_gemm_nt_swiglu_fwd(const void* X, long ldx, const void* W13, 
     if (256L * ldx * 2 >= 0x7ff00000L || 2L * F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)X, ldx, (const bf16_t*)W13, ldw, ab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_FWD,
-             nullptr, 0, (bf16_t*)h, ld_h};
+             nullptr, 0, (bf16_t*)h, ld_h, nullptr, nullptr};
     const int tiles = ((M + 255) / 256) * (F / 128);
     EGO_LAUNCH(gemm_nt256_kernel<3>, dim3(tiles < 256 ? tiles : 256), dim3(512), NT3_LDS, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+// ---- fp8 (OCP e4m3) forward linears: BASELINE config 5 ("bf16 + fp8 MFMA GEMMs") --------------------------------------
+extern "C" int ego_gemm_nt_fp8(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, long ldc,
+                               const float* R, long ldr, const float* bias, int M, int N, int K, int epi, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return EGO_OK;
+    // one kernel family only (persistent 256x256): K in whole 128-byte tiles, at least two of them
+    if (K < 256 || K % 128 || N % 128 || lda % 16 || ldb % 16 || ldc % 4 || epi < 0 || epi > EGO_EPI_BIAS_RESID || !sa || !sb) return EGO_ERR_ARG;
+    if (epi == EGO_EPI_BF16 && ldc % 8) return EGO_ERR_ARG;
+    if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
+    if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
+    if (256L * lda >= 0x7ff00000L || (long)N * ldb >= 0xfff00000L) return EGO_ERR_ARG;
+    ensure_attrs();
+    NTArgs a{(const bf16_t*)A8, lda, (const bf16_t*)B8, ldb, C, ldc, R, ldr, bias, nullptr, M, N, K, epi, nullptr, 0, nullptr, 0, sa, sb};
+    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    if (epi == EGO_EPI_BF16) { EGO_LAUNCH((gemm_nt256_kernel<0, true>), dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+    else { EGO_LAUNCH((gemm_nt256_kernel<1, true>), dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_gemm_nt_swiglu_fwd_fp8(const void* X8, long ldx, const float* sx, const void* W13_8, long ldw, const float* sw,
+                                          void* ab, long ld_ab, void* h, long ld_h, int M, int F, int K, hipStream_t stream) {
+    if (M <= 0) return EGO_OK;
+    if (F % 128 || K % 128 || K < 256 || ldx % 16 || ldw % 16 || ld_ab % 8 || ld_h % 8 || ld_ab < 2L * F || ld_h < F || !sx || !sw) return EGO_ERR_ARG;
+    if (256L * ldx >= 0x7ff00000L || 2L * F * ldw >= 0xfff00000L) return EGO_ERR_ARG;
+    ensure_attrs();
+    NTArgs a{(const bf16_t*)X8, ldx, (const bf16_t*)W13_8, ldw, ab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_FWD,
+             nullptr, 0, (bf16_t*)h, ld_h, sx, sw};
+    const int tiles = ((M + 255) / 256) * (F / 128);
+    EGO_LAUNCH((gemm_nt256_kernel<3, true>), dim3(tiles < 256 ? tiles : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -1127,7 +1202,7 @@ extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t,
     if (256L * ldy * 2 >= 0x7ff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)W2t, ldw, dab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_BWD,
-             (const bf16_t*)ab, ld_ab, nullptr, 0};
+             (const bf16_t*)ab, ld_ab, nullptr, 0, nullptr, nullptr};
     const int tiles256 = ((M + 255) / 256) * (F / 256);
     EGO_LAUNCH(gemm_nt256_kernel<2>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();

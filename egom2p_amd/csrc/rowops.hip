@@ -18,7 +18,8 @@ template <int LN_MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, const int* __restrict__ out_row,
-                                                     int rows, int D, float eps) {
+                                                     int rows, int D, float eps, unsigned char* __restrict__ q8, long ldq,
+                                                     float* __restrict__ qscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -46,14 +47,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int orow = out_row ? out_row[row] : row;
     if (orow < 0) return;
     bf16_t* yr = y + (long)orow * D;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nc) {
             const f32x4 ww = *(const f32x4*)(w + c * 4);
-            u32x2 o = {pack_bf16x2((v[i][0] - mean) * rstd * ww[0], (v[i][1] - mean) * rstd * ww[1]),
-                       pack_bf16x2((v[i][2] - mean) * rstd * ww[2], (v[i][3] - mean) * rstd * ww[3])};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = round_bf16((v[i][e] - mean) * rstd * ww[e]); amax = fmaxf(amax, fabsf(v[i][e])); }
+            u32x2 o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3])};
             *(u32x2*)(yr + c * 4) = o;
+        }
+    }
+    // optional e4m3 copy of the row for an fp8 GEMM (bit for bit what ego_quant_fp8_rows makes of the bf16 row)
+    if (q8) {
+        amax = wave_max(amax);
+        const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f, inv = 1.f / sc;
+        if (lane == 0) qscale[orow] = sc;
+        unsigned char* qr = q8 + (long)orow * ldq;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                int wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+                wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, wd, true);
+                *(int*)(qr + c * 4) = wd;
+            }
         }
     }
 }
@@ -382,15 +401,50 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     }
 }
 
+// Row-wise fp8 quantisation (OCP e4m3, max 448): scale[r] = amax(row) / 448 (1 for an all-zero row), q = e4m3(x / scale).
+// One wave per row, 16 bytes of bf16 per lane and pass; HBM-bound: 2 B read + 1 B written per element.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ X, long ld, long rows, int K,
+                                                              unsigned char* __restrict__ Q, long ldq, float* __restrict__ scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16_t* x = X + row * ld;
+    float amax = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        const u32x4 v = *(const u32x4*)(x + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf16_to_f32(v[e] & 0xffff)), fabsf(bf16_to_f32(v[e] >> 16))));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f, inv = 1.f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned char* q = Q + row * ldq;
+    for (int c = lane * 8; c < K; c += 512) {
+        const u32x4 v = *(const u32x4*)(x + c);
+        u32x2 o;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float f0 = bf16_to_f32(v[2 * e] & 0xffff) * inv, f1 = bf16_to_f32(v[2 * e] >> 16) * inv;
+            const float f2 = bf16_to_f32(v[2 * e + 1] & 0xffff) * inv, f3 = bf16_to_f32(v[2 * e + 1] >> 16) * inv;
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, w, true);
+            o[e] = (unsigned)w;
+        }
+        *(u32x2*)(q + c) = o;
+    }
+}
+
 inline int grid_for(long total, int cap = 4096) { return (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap); }
 
 }  // namespace
 
 extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd,
-                                 const int* out_row, int rows, int D, float eps, hipStream_t stream) {
+                                 const int* out_row, int rows, int D, float eps, void* q8, long ldq, float* qscale,
+                                 hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
-#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps)
+    if (D % 4 || D > LN_MAXC_MAX * 256 || (q8 && (!qscale || ldq % 4))) return EGO_ERR_ARG;
+#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps, \
+                             (unsigned char*)q8, ldq, qscale)
     if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else if (D <= 1536) LN_FWD(6); else LN_FWD(8);
 #undef LN_FWD
     LAUNCH_CHECK();
@@ -474,6 +528,15 @@ extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, hipStre
     const int rgroups = 256 / (D / 8);
     EGO_LAUNCH(bias_grad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)rgroups * D * sizeof(float), stream,
                (const bf16_t*)g, rows, D, db);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_quant_fp8_rows(const void* X, long ld, long rows, int K, void* Q, long ldq, float* scale, hipStream_t stream) {
+    if (rows <= 0) return EGO_OK;
+    if (K <= 0 || K % 8 || ld % 8 || ldq % 8) return EGO_ERR_ARG;
+    EGO_LAUNCH(quant_fp8_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, ld, rows, K, (unsigned char*)Q, ldq,
+               scale);
     LAUNCH_CHECK();
     return EGO_OK;
 }

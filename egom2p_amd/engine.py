@@ -37,24 +37,32 @@ def _pad128(n: int) -> int:
 
 
 class _Lin:
-    """One linear layer: master view [out, in] (possibly padded), bf16 W [out, in] and W^T [in, out]."""
-    __slots__ = ("name", "w", "g", "wb", "wt", "out_f", "in_f")
+    """One linear layer: master view [out, in] (possibly padded), bf16 W [out, in] and W^T [in, out]; with the fp8
+    forward enabled also W as OCP e4m3 bytes with one fp32 scale per output channel."""
+    __slots__ = ("name", "w", "g", "wb", "wt", "out_f", "in_f", "w8", "s8")
 
-    def __init__(self, name, w, g, dev):
+    def __init__(self, name, w, g, dev, fp8=False):
         self.name, self.w, self.g = name, w, g
         self.out_f, self.in_f = w.shape
         self.wb = torch.zeros(self.out_f, self.in_f, device=dev, dtype=BF16)
         self.wt = torch.zeros(self.in_f, self.out_f, device=dev, dtype=BF16)
+        ok8 = fp8 and self.in_f % 128 == 0 and self.in_f >= 256 and self.out_f % 128 == 0
+        self.w8 = torch.zeros(self.out_f, self.in_f, device=dev, dtype=torch.uint8) if ok8 else None
+        self.s8 = torch.ones(self.out_f, device=dev, dtype=F32) if ok8 else None
 
 
 class Engine:
     def __init__(self, cfg: ModelCfg, device="cuda:0", max_batch: int = 1, n_enc: int = 2048, n_dec: int = 2048,
-                 attn_o_residual: str = "cross"):
+                 attn_o_residual: str = "cross", fp8_forward: bool = False):
         """attn_o_residual: which attention sites also keep the bf16 rounding residual of their output so that the
         backward's delta = rowsum(dO o O) is formed from O to ~16 bits ("cross": the cross-attention sites - where, with
         near-uniform attention over ~2000 context keys, the plain flash-style delta put 3.5 % error on the query-path
         gradients; "all"; "none").  Costs one more bf16 [rows, D] write + read per site (~0.5 % of a step for "cross")."""
         L.load()  # fail loudly if the HIP library is missing
+        # fp8_forward (BASELINE config 5, "bf16 + fp8 MFMA GEMMs"): the forward linears (qkv / q / kv / proj / fc1||fc3 / fc2 /
+        # context projection) run on e4m3 operands - activations quantised per row right before the GEMM, weights per
+        # output channel once per optimiser step - with fp32 accumulation; the backward and the logits stay bf16.
+        self.fp8_forward = bool(fp8_forward)
         if attn_o_residual not in ("cross", "all", "none"):
             raise ValueError("attn_o_residual must be 'cross', 'all' or 'none'")
         self.attn_o_residual = attn_o_residual
@@ -181,7 +189,7 @@ class Engine:
         self.lin: Dict[str, _Lin] = {}
 
         def lin(name):
-            self.lin[name] = _Lin(name, self.p[name], self.g[name], self.dev)
+            self.lin[name] = _Lin(name, self.p[name], self.g[name], self.dev, fp8=self.fp8_forward and "token_emb" not in name and "to_logits" not in name)
 
         for i in range(cfg.encoder_depth):
             for s in ("attn.qkv", "attn.proj", "mlp.fc2"):
@@ -205,7 +213,7 @@ class Engine:
         n = 2 * self.Fp * self.D
         w = self.P[o1:o1 + n].view(2 * self.Fp, self.D)
         g = self.G[o1:o1 + n].view(2 * self.Fp, self.D)
-        self.lin[f"{prefix}.mlp.fc13"] = _Lin(f"{prefix}.mlp.fc13", w, g, self.dev)
+        self.lin[f"{prefix}.mlp.fc13"] = _Lin(f"{prefix}.mlp.fc13", w, g, self.dev, fp8=self.fp8_forward)
 
     # reference key layout <-> engine storage ----------------------------------------------------
     def _view_for_key(self, key: str) -> Optional[torch.Tensor]:
@@ -322,6 +330,8 @@ class Engine:
         """fp32 masters -> bf16 W and W^T copies (once per optimiser step; autocast re-casts per forward)."""
         for name, l in self.lin.items():
             ops.cast_weight(l.w, l.wb, l.wt)
+            if l.w8 is not None:
+                ops.quant_fp8_rows(l.wb, l.w8, l.s8)
         self.weights_dirty = False
 
     # ------------------------------------------------------------------------------------ workspaces
@@ -396,17 +406,55 @@ class Engine:
         self.dyn = torch.zeros(RM, D, device=dev, dtype=BF16)
         self.delta = e(B, H, max(N, M), dt=F32)
         self.slab = e(64 * 1024 * 1024 // 4, dt=F32)   # 64 MiB of split-K partials (256 workgroups x 256 KiB)
+        if self.fp8_forward:                           # e4m3 copy + row scales of the current GEMM input
+            self.q8 = e(R, max(D, Fp), dt=torch.uint8)
+            self.qs = e(R, dt=F32)
         self.gscale = torch.ones(1, device=dev, dtype=F32)
 
     # ------------------------------------------------------------------------------------ small helpers
+    def _ln(self, x, wname, y, st, out_row=None):
+        """LayerNorm forward; with the fp8 forward on, the row also leaves as e4m3 (+ scale) for the GEMM that follows
+        (no separate quantisation pass for the LayerNorm-fed linears)."""
+        rows = x.shape[0]
+        if self.fp8_forward and out_row is None and self.D % 128 == 0 and self.D >= 256:
+            q = self._qbuf(rows, self.D)
+            ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], eps=self.cfg.eps, q8=q, qscale=self.qs)
+            self._q_of = (y.data_ptr(), rows, self.D)
+        else:
+            ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], out_row=out_row, eps=self.cfg.eps)
+
+    def _qbuf(self, rows, K):
+        if getattr(self, "q8", None) is None or self.q8.shape[0] < rows:
+            self.q8 = torch.empty(rows, max(self.D, self.Fp), device=self.dev, dtype=torch.uint8)
+            self.qs = torch.empty(rows, device=self.dev, dtype=F32)
+        self._q_of = None
+        return self.q8[:, :K]
+
+    def _quant(self, A, rows, K):
+        """e4m3 copy of the first `rows` rows of A (row scales in self.qs); the buffers are reused by the next GEMM input"""
+        if getattr(self, "_q_of", None) == (A.data_ptr(), rows, K):      # the LayerNorm that made A already left its e4m3 copy
+            self._q_of = None
+            return self.q8[:, :K]
+        q = self._qbuf(rows, K)
+        ops.quant_fp8_rows(A, q, self.qs, rows=rows, K=K)
+        return q
+
     def _lin_fwd(self, name, A, C, rows, epi=L.EPI_BF16, R=None, bias=None):
         l = self.lin[name]
+        if l.w8 is not None and rows > 0:
+            q = self._quant(A, rows, l.in_f)
+            ops.gemm_nt_fp8(q, self.qs, l.w8, l.s8, C, rows, l.out_f, l.in_f, epi, R=R, bias=bias)
+            return
         ops.gemm_nt(A, l.wb, C, rows, l.out_f, l.in_f, epi, R=R, bias=bias, lda=A.shape[-1], ldb=l.in_f, ldc=C.shape[-1],
                     ldr=None if R is None else R.shape[-1])
 
     def _mlp_gate_fwd(self, pre, xn, ab, h, rows):
         """ab = fc1||fc3(xn), h = silu(a) * b - one launch where the shape allows it"""
         l = self.lin[f"{pre}.mlp.fc13"]
+        if l.w8 is not None and rows > 0:
+            q = self._quant(xn, rows, l.in_f)
+            ops.gemm_nt_swiglu_fwd_fp8(q, self.qs, l.w8, l.s8, ab, h, rows, self.Fp, l.in_f)
+            return
         if ops.swiglu_fwd_fusable(self.Fp, l.in_f) and rows >= 4096:
             ops.gemm_nt_swiglu_fwd(xn, l.wb, ab, h, rows, self.Fp, l.in_f, ldx=xn.shape[-1], ldw=l.in_f)
         else:
@@ -495,17 +543,17 @@ class Engine:
         for i, w in enumerate(self.enc):
             pre = f"encoder.{i}"
             nxt = self.enc[i + 1]["x"] if i + 1 < cfg.encoder_depth else self.x_enc_out
-            ops.layernorm_fwd(w["x"][:RN], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
+            self._ln(w["x"][:RN], f"{pre}.norm1.weight", w["ln1"], w["st1"])
             self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln1"], w["qkv"], RN)
             # key-padding mask = one interval [0, n_valid) per SAMPLE (the per-row copies ce["ks"/"ke"] hold the same
             # numbers): the uniform form lets the attention kernels walk one (batch, head) pair per XCD (L2-resident K / V)
             self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N,
                        o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
-            ops.layernorm_fwd(w["xm"][:RN], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
+            self._ln(w["xm"][:RN], f"{pre}.norm2.weight", w["ln2"], w["st2"])
             self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RN)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RN, L.EPI_RESID, R=w["xm"])
-        ops.layernorm_fwd(self.x_enc_out[:RN], self.p["encoder_norm.weight"], self.xe, self.st_en[0], self.st_en[1], eps=cfg.eps)
+        self._ln(self.x_enc_out[:RN], "encoder_norm.weight", self.xe, self.st_en)
         # context = decoder_proj_context(x) + encoder_emb   (egom2p_model.py:722)
         self._lin_fwd("decoder_proj_context.weight", self.xe, self.ctx, RN, L.EPI_BIAS_RESID, R=self.emb_e,
                       bias=self.p["decoder_proj_context.bias"])
@@ -514,19 +562,19 @@ class Engine:
         for i, w in enumerate(self.dec):
             pre = f"decoder.{i}"
             nxt = self.dec[i + 1]["x"] if i + 1 < cfg.decoder_depth else self.y_out
-            ops.layernorm_fwd(w["x"][:RM], self.p[f"{pre}.norm1.weight"], w["ln1"], w["st1"][0], w["st1"][1], eps=cfg.eps)
+            self._ln(w["x"][:RM], f"{pre}.norm1.weight", w["ln1"], w["st1"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln1"], w["qkv"], RM)
             self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M,
                        o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
-            ops.layernorm_fwd(w["x1"][:RM], self.p[f"{pre}.query_norm.weight"], w["qn"], w["stq"][0], w["stq"][1], eps=cfg.eps)
+            self._ln(w["x1"][:RM], f"{pre}.query_norm.weight", w["qn"], w["stq"])
             self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
-            ops.layernorm_fwd(self.ctx[:RN], self.p[f"{pre}.context_norm.weight"], w["cn"], w["stc"][0], w["stc"][1], eps=cfg.eps)
+            self._ln(self.ctx[:RN], f"{pre}.context_norm.weight", w["cn"], w["stc"])
             self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
             self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N,
                        o_lo=w["xo_lo"])
             self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["xo"], w["x2"], RM, L.EPI_RESID, R=w["x1"])
-            ops.layernorm_fwd(w["x2"][:RM], self.p[f"{pre}.norm2.weight"], w["ln2"], w["st2"][0], w["st2"][1], eps=cfg.eps)
+            self._ln(w["x2"][:RM], f"{pre}.norm2.weight", w["ln2"], w["st2"])
             self._mlp_gate_fwd(pre, w["ln2"], w["ab"], w["h"], RM)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RM, L.EPI_RESID, R=w["x2"])
         # decoder_norm, rows written modality-grouped (the row order of y[decoder_mod_mask == id], :633)
@@ -757,14 +805,14 @@ class Engine:
                           x, w["emb"], RN, D)
             for i in range(cfg.encoder_depth):
                 pre = f"encoder.{i}"
-                ops.layernorm_fwd(x[:RN], self.p[f"{pre}.norm1.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
                 self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
                 self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
-                ops.layernorm_fwd(xn[:RN], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
                 self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
                 self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
-            ops.layernorm_fwd(x[:RN], self.p["encoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._ln(x[:RN], "encoder_norm.weight", w["ln"], w["st"])
             self._lin_fwd("decoder_proj_context.weight", w["ln"], w["ctx"], RN, L.EPI_BIAS_RESID, R=w["emb"],
                           bias=self.p["decoder_proj_context.bias"])
         # decoder rows: mask token + positional + modality embedding of the selected target positions (:481-516)
@@ -775,14 +823,14 @@ class Engine:
         w["full_m"].fill_(M)
         for i in range(cfg.decoder_depth):
             pre = f"decoder.{i}"
-            ops.layernorm_fwd(y[:RM], self.p[f"{pre}.norm1.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._ln(y[:RM], f"{pre}.norm1.weight", w["ln"], w["st"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RM)
             self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], w["full_m"], 1, 0, B, M, M)
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RM, L.EPI_RESID, R=y)
             if N > 0:
-                ops.layernorm_fwd(yn[:RM], self.p[f"{pre}.query_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._ln(yn[:RM], f"{pre}.query_norm.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RM)
-                ops.layernorm_fwd(w["ctx"][:RN], self.p[f"{pre}.context_norm.weight"], w["cn"], w["st"][0], w["st"][1], eps=cfg.eps)
+                self._ln(w["ctx"][:RN], f"{pre}.context_norm.weight", w["cn"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
                 self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, M, N)
                 self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RM, L.EPI_RESID, R=yn)
@@ -790,11 +838,11 @@ class Engine:
                 # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the
                 # bias-free proj keeps it 0, so the cross-attention residual is the identity
                 y, yn = yn, y
-            ops.layernorm_fwd(y[:RM], self.p[f"{pre}.norm2.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+            self._ln(y[:RM], f"{pre}.norm2.weight", w["ln"], w["st"])
             self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RM)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RM, L.EPI_RESID, R=y)
             y, yn = yn, y
-        ops.layernorm_fwd(y[:RM], self.p["decoder_norm.weight"], w["ln"], w["st"][0], w["st"][1], eps=cfg.eps)
+        self._ln(y[:RM], "decoder_norm.weight", w["ln"], w["st"])
         l = self.lin[self.logit_key[tm.name]]
         logits = out if out is not None else torch.empty(RM, tm.vocab_size, device=self.dev, dtype=BF16)
         ops.gemm_nt(w["ln"], l.wb, logits, RM, tm.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=tm.vocab_size)

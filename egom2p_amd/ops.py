@@ -29,11 +29,11 @@ def _need_cuda(*ts):
 
 
 # ------------------------------------------------------------------------------------------
-def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6):
+def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None):
     _need_cuda(x)
     rows, D = x.shape
-    check(L.load().ego_layernorm_fwd(_p(x), _p(w), _p(y), _p(mean), _p(rstd), _p(out_row), rows, D, eps, _stream()),
-          "ego_layernorm_fwd")
+    check(L.load().ego_layernorm_fwd(_p(x), _p(w), _p(y), _p(mean), _p(rstd), _p(out_row), rows, D, eps, _p(q8),
+                                     0 if q8 is None else q8.stride(-2), _p(qscale), _stream()), "ego_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
@@ -52,6 +52,26 @@ def gemm_nt(A, B, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None, m_range=Non
     ldr = 0 if R is None else (R.stride(-2) if ldr is None else ldr)
     check(L.load().ego_gemm_nt_bf16(_p(A), lda, _p(B), ldb, _p(C_out), ldc, _p(R), ldr, _p(bias), _p(m_range), M, N, K, epi,
                                     _stream()), "ego_gemm_nt_bf16")
+
+
+def quant_fp8_rows(X, Q, scale, rows=None, K=None):
+    """Q (uint8 e4m3) = X (bf16) / scale[row], scale[row] = amax(row) / 448."""
+    _need_cuda(X)
+    rows = X.shape[0] if rows is None else rows
+    K = X.shape[-1] if K is None else K
+    check(L.load().ego_quant_fp8_rows(_p(X), X.stride(-2), rows, K, _p(Q), Q.stride(-2), _p(scale), _stream()), "ego_quant_fp8_rows")
+
+
+def gemm_nt_fp8(A8, sa, B8, sb, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None):
+    """C[M,N] = sa[:,None] * sb[None,:] * (A8[M,K] @ B8[N,K]^T) over e4m3 operands (+ epilogue)."""
+    _need_cuda(A8)
+    check(L.load().ego_gemm_nt_fp8(_p(A8), A8.stride(-2), _p(sa), _p(B8), B8.stride(-2), _p(sb), _p(C_out), C_out.stride(-2), _p(R),
+                                   0 if R is None else R.stride(-2), _p(bias), M, N, K, epi, _stream()), "ego_gemm_nt_fp8")
+
+
+def gemm_nt_swiglu_fwd_fp8(X8, sx, W8, sw, ab, h, M, F, K):
+    check(L.load().ego_gemm_nt_swiglu_fwd_fp8(_p(X8), X8.stride(-2), _p(sx), _p(W8), W8.stride(-2), _p(sw), _p(ab), ab.stride(-2), _p(h),
+                                              h.stride(-2), M, F, K, _stream()), "ego_gemm_nt_swiglu_fwd_fp8")
 
 
 def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_range=None, splits=1, slab=None,

@@ -99,8 +99,8 @@ class KernelTimer:
                 return 0.0, 0.0
             return c
 
-        def c_ln_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6):
-            return 0.0, x.shape[0] * x.shape[1] * 6.0
+        def c_ln_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None):
+            return 0.0, x.shape[0] * x.shape[1] * (7.0 if q8 is not None else 6.0)
 
         def c_ln_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
             n = x.shape[0] * x.shape[1]
@@ -120,7 +120,19 @@ class KernelTimer:
             n = int(rng[1].item())
             return 0.0, n * V * 4.0
 
+        def c_gemm_nt_fp8(A8, sa, B8, sb, C, M, N, K, epi=0, R=None, bias=None):
+            return 2.0 * M * N * K, 1.0 * (M * K + N * K) + (2.0 if epi == 0 else 8.0) * M * N
+
+        def c_gemm_nt_swiglu_fwd_fp8(X8, sx, W8, sw, ab, h, M, F, K):
+            return 4.0 * M * F * K, 1.0 * (M * K + 2 * F * K) + 6.0 * M * F
+
+        def c_quant(X, Q, scale, rows=None, K=None):
+            r = X.shape[0] if rows is None else rows
+            k = X.shape[-1] if K is None else K
+            return 0.0, 3.0 * r * k
+
         table = {
+            "gemm_nt_fp8": c_gemm_nt_fp8, "gemm_nt_swiglu_fwd_fp8": c_gemm_nt_swiglu_fwd_fp8, "quant_fp8_rows": c_quant,
             "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_nt_swiglu_fwd": c_gemm_nt_swiglu_fwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
             "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
             "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
@@ -135,7 +147,7 @@ class KernelTimer:
             n_rw = (1 if tables is not None else 0) + 1 + 1 + (1 if emb is not None else 0)   # token row, pos row | x, emb
             return 0.0, float(rows) * D * 4 * n_rw + rows * 12.0
 
-        def c_embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D):
+        def c_embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D, touched=None):
             n_rw = 1 + (1 if d2 is not None else 0) + (1 if dtables is not None else 0)       # dx, d2 | table rows (atomic adds)
             return 0.0, float(rows) * D * 4 * n_rw + rows * 8.0
 
@@ -163,6 +175,7 @@ class KernelTimer:
         other = {"compact": c_compact, "embed_fwd": c_embed_fwd, "embed_bwd": c_embed_bwd, "loss_perm": c_loss_perm,
                  "loss_finalize": c_loss_finalize, "cast_weight": c_cast_weight, "cast_f32_bf16": c_cast, "bias_grad": c_bias_grad,
                  "grad_sqnorm": c_sqnorm, "adamw_step": c_adamw}
+        self.cost_table = dict(table, **other)
         saved = {}
         # the fused launches are the same device kernel (gemm_nt256_kernel<EK>) behind other entry points: one class
         family = {"gemm_nt_swiglu_fwd": "gemm_nt", "gemm_nt_swiglu_bwd": "gemm_nt"}

@@ -107,9 +107,10 @@ int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* 
 /* ---- transformer blocks ---------------------------------------------------------------------- */
 
 /* Bias-free LayerNorm (egom2p/models/egom2p_utils.py:118-133): y(bf16)[out_row[r]] = LN(x[r]) * w.
- * out_row may be NULL (identity); -1 drops the row. mean/rstd are saved for the backward. */
+ * out_row may be NULL (identity); -1 drops the row. mean/rstd are saved for the backward.  q8 / qscale (optional): the
+ * row also leaves as e4m3 bytes + scale, exactly what ego_quant_fp8_rows would make of y (operand of an fp8 GEMM). */
 int ego_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* mean, float* rstd, const int* out_row,
-                      int rows, int D, float eps, hipStream_t stream);
+                      int rows, int D, float eps, void* q8, long ldq, float* qscale, hipStream_t stream);
 /* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row. */
 int ego_layernorm_bwd(const void* dy_bf16, const int* dy_row, const float* x, const float* mean, const float* rstd,
                       const float* w, const float* dx_in, float* dx_out, void* dx_out_bf16, float* dw, int rows, int D,
@@ -127,6 +128,17 @@ int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
 int ego_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, float* C0, float* C1, long ldc, int split_row,
                      int rows0, int rows1, const int* m_range, int Ni, int Nj, int M, int splits, float* slab,
                      hipStream_t stream);
+
+/* fp8 forward linears (BASELINE config 5: "bf16 + fp8 MFMA GEMMs"; the reference has no fp8 path - the contract is the
+ * same F.linear, egom2p_utils.py:141-169, 180-203, 215-242, to a stated tolerance).  Operands are OCP e4m3 bytes with one
+ * fp32 scale per row (activations) / per output channel (weights): C[m,n] = sa[m] * sb[n] * sum_k A8[m,k] B8[n,k], MFMA
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with fp32 accumulation, same epilogues as ego_gemm_nt_bf16.  K % 128 == 0, K >= 256,
+ * N % 128 == 0.  ego_quant_fp8_rows makes the operands: scale[r] = amax(row r) / 448, Q = e4m3(X / scale). */
+int ego_quant_fp8_rows(const void* X_bf16, long ld, long rows, int K, void* Q, long ldq, float* scale, hipStream_t stream);
+int ego_gemm_nt_fp8(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, void* C, long ldc,
+                    const float* R, long ldr, const float* bias, int M, int N, int K, int epi, hipStream_t stream);
+int ego_gemm_nt_swiglu_fwd_fp8(const void* X8, long ldx, const float* sx, const void* W13_8, long ldw, const float* sw,
+                               void* ab, long ld_ab, void* h, long ld_h, int M, int F, int K, hipStream_t stream);
 
 /* Split-K factor `splits` the wgrad above should be called with for this shape (>= 1; 1 when the row range lives on the
  * device): one round of workgroups, bounded by the slab the caller owns (slab_elems fp32).  The launcher's own rule -

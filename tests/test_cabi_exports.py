@@ -39,3 +39,28 @@ def test_no_oracle_import_in_product_path():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_profiler_cost_functions_accept_the_ops_signatures():
+    """bench.py wraps every `ops` entry with a cost function of the same signature: a keyword added to an op but not to
+    its cost function only fails on the GPU box, inside the bench - check the binding here."""
+    import inspect
+    from unittest import mock
+    import torch
+    from egom2p_amd import ops
+    from egom2p_amd.profiler import KernelTimer
+    kt = KernelTimer()
+    with mock.patch.object(torch.cuda, "Event", lambda **k: None):
+        with kt.capture(12):
+            table = dict(kt.cost_table)
+    for name, cost in table.items():
+        op = inspect.signature(getattr(ops, name))
+        cs = inspect.signature(cost)
+        var_pos = any(p.kind == p.VAR_POSITIONAL for p in cs.parameters.values())
+        var_kw = any(p.kind == p.VAR_KEYWORD for p in cs.parameters.values())
+        n_pos_op = sum(1 for p in op.parameters.values() if p.default is p.empty)
+        n_pos_cost = sum(1 for p in cs.parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD))
+        assert var_pos or n_pos_cost >= n_pos_op, f"cost function of ops.{name} takes fewer positional arguments than the op"
+        for n, p in op.parameters.items():                   # parameters with defaults are the ones callers pass by keyword
+            if p.default is not p.empty:
+                assert n in cs.parameters or var_kw, f"profiler cost function of ops.{name} does not accept keyword '{n}'"

@@ -494,3 +494,65 @@ def test_attention_kernels_are_deterministic_under_load():
         noise.normal_()
         o, l, d = run()
         assert torch.equal(o, o0) and torch.equal(l, l0) and torch.equal(d, d0), it
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1000, 768, 768, "bf16"), (512, 2304, 768, "bf16"), (700, 768, 2048, "resid"), (384, 1152, 1152, "bias_resid")])
+def test_gemm_nt_fp8_against_dequantised_operands(M, N, K, epi):
+    """BASELINE config 5: e4m3 operands with per-row / per-output-channel scales on v_mfma_scale_f32_16x16x128_f8f6f4.
+    (1) exact contract: equals an fp32 matmul of the DEQUANTISED operands up to summation order - checks the operand
+    layout, the K-tiling in 128-byte steps, the scale application and every epilogue; (2) accuracy: within e4m3's
+    quantisation noise of the bf16 product (3 mantissa bits: ~2^-4 / sqrt(3) per operand element, averaging over K)."""
+    torch.manual_seed(M + N)
+    A = (torch.randn(M, K, device=DEV) * torch.rand(M, 1, device=DEV) * 3).bfloat16()         # rows of different magnitude
+    B = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    A8 = torch.empty(M, K, device=DEV, dtype=torch.uint8); sa = torch.empty(M, device=DEV)
+    B8 = torch.empty(N, K, device=DEV, dtype=torch.uint8); sb = torch.empty(N, device=DEV)
+    ops.quant_fp8_rows(A, A8, sa)
+    ops.quant_fp8_rows(B, B8, sb)
+    # quantiser: scale = amax / 448, values round-to-nearest e4m3
+    assert torch.allclose(sa, A.float().abs().amax(1) / 448.0, rtol=1e-6)
+    Ad = A8.view(torch.float8_e4m3fn).float() * sa[:, None]
+    Bd = B8.view(torch.float8_e4m3fn).float() * sb[:, None]
+    assert float((Ad - A.float()).abs().max() / A.float().abs().max()) < 2.0 ** -4
+    ref = Ad.double() @ Bd.double().t()
+    R = torch.randn(M, N, device=DEV)
+    bias = torch.randn(N, device=DEV)
+    if epi == "bf16":
+        C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt_fp8(A8, sa, B8, sb, C, M, N, K, L.EPI_BF16)
+        want = ref.float().bfloat16().float()
+        tol = 2.0 ** -8
+    elif epi == "resid":
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm_nt_fp8(A8, sa, B8, sb, C, M, N, K, L.EPI_RESID, R=R)
+        want = R + ref.float().bfloat16().float()
+        tol = 2.0 ** -8
+    else:
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm_nt_fp8(A8, sa, B8, sb, C, M, N, K, L.EPI_BIAS_RESID, R=R, bias=bias)
+        want = R + (ref.float() + bias.bfloat16().float()).bfloat16().float()
+        tol = 2.0 ** -8
+    torch.cuda.synchronize()
+    err = (C.float() - want).abs().max() / want.abs().max()
+    assert float(err) < tol, float(err)                                  # one bf16 ulp of slack for the output rounding
+    exact = (A.double() @ B.double().t()).float()
+    got = C.float() - (0 if epi == "bf16" else R) - (bias.bfloat16().float() if epi == "bias_resid" else 0)
+    rel = float((got - exact).norm() / exact.norm())
+    assert rel < 4e-2, rel                                               # e4m3 quantisation noise of both operands
+
+
+def test_fused_fc13_gate_fp8_equals_two_call_form():
+    M, F, K = 1280, 2048, 768
+    torch.manual_seed(3)
+    X = torch.randn(M, K, device=DEV).bfloat16()
+    W = (torch.randn(2 * F, K, device=DEV) * 0.04).bfloat16()
+    X8 = torch.empty(M, K, device=DEV, dtype=torch.uint8); sx = torch.empty(M, device=DEV)
+    W8 = torch.empty(2 * F, K, device=DEV, dtype=torch.uint8); sw = torch.empty(2 * F, device=DEV)
+    ops.quant_fp8_rows(X, X8, sx); ops.quant_fp8_rows(W, W8, sw)
+    ab = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16); h = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt_swiglu_fwd_fp8(X8, sx, W8, sw, ab, h, M, F, K)
+    ab2 = torch.empty_like(ab); h2 = torch.empty_like(h)
+    ops.gemm_nt_fp8(X8, sx, W8, sw, ab2, M, 2 * F, K, L.EPI_BF16)
+    ops.swiglu_fwd(ab2, h2, M, F)
+    torch.cuda.synchronize()
+    assert torch.equal(ab, ab2) and torch.equal(h, h2)
