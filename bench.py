@@ -58,8 +58,9 @@ def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
         loss.backward()
         return time.time() - t0, float(loss.item())
 
-    plan = ([(1, "fp32", 1, 5), (4, "fp32", 1, 5), (1, "bf16", 1, 5), (4, "bf16", 1, 5)] if protocol == "full"
-            else [(1, "fp32", 1, 3), (1, "bf16", 0, 1)])
+    full = [(1, "fp32", 1, 5), (4, "fp32", 1, 5), (1, "bf16", 1, 5), (4, "bf16", 1, 5)]
+    plan = {"quick": [(1, "fp32", 1, 3), (1, "bf16", 0, 1)], "full": full,
+            "full-fp32": full[:2], "full-bf16": [full[0][:3] + (1,)] + full[2:]}[protocol]   # halves of "full" for a 20-minute box limit
     runs, total = [], 0.0
     for B, mode, n_warm, n_timed in plan:
         md = synth.make_clip_batch(cfg, B, budgets, seed=100 + rank, sample_offset=0)      # the GPU run's first clips, host copy
@@ -69,6 +70,7 @@ def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
         for _ in range(n_timed):
             t, loss = once(md, mode)
             ts.append(t)
+            print(f"[cpu_baseline] B={B} {mode}: {t:.1f} s", file=sys.stderr, flush=True)
         total += sum(ts)
         med = statistics.median(ts)
         runs.append({"batch": B, "mode": mode, "warmup": n_warm, "timed": n_timed, "median_s": round(med, 3),
@@ -89,7 +91,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
+    ap.add_argument("--cpu-baseline", choices=["quick", "full", "full-fp32", "full-bf16"], default="quick",
                     help="quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; full: SURVEY 8(d) protocol (~15 min)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)

@@ -90,13 +90,19 @@ class SparseTableExchange:
     rank order into the table - the same result as the dense sum (identical on every rank: one fixed order), moving
     (world - 1) * cap_rows rows instead of 2 (world - 1) / world * V.  `worth_it` is that byte comparison.
 
-    Works on CPU tensors too (gloo rehearsal in tests/test_dp_gloo.py); on the GPU the compaction / gather / scatter are
-    the ego_rows_* kernels."""
+    The compaction / gather / scatter are the ego_rows_* HIP kernels; `prims` replaces them only in the CPU rehearsal of
+    the collective pattern (tests/test_dp_gloo.py passes its own torch-indexing object) - the product has no CPU path."""
 
-    def __init__(self, tables, cap_rows: int, process_group=None):
+    def __init__(self, tables, cap_rows: int, process_group=None, prims=None):
         """tables: list of (grad view [V, D] fp32, touched flags uint8 [V])."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if prims is None:
+            from . import ops                                  # raises if the HIP library is missing
+            if not all(g.is_cuda for g, _ in tables):
+                raise RuntimeError("SparseTableExchange: table gradients must live on the GPU (HIP row kernels)")
+            prims = ops
+        self.prims = prims
         self.tables = []
         for g, touched in tables:
             V, D = g.shape
@@ -115,44 +121,14 @@ class SparseTableExchange:
         dense = 2.0 * (world - 1) / world * V * D * 4
         return world > 1 and gather < dense
 
-    # --- the three primitives: HIP kernels on the GPU, torch indexing on CPU tensors (gloo rehearsal only)
-    @staticmethod
-    def _compact(t):
-        if t["g"].is_cuda:
-            from . import ops
-            ops.rows_compact(t["touched"], t["cap"], t["rows"], t["count"])
-        else:
-            idx = torch.nonzero(t["touched"]).flatten().to(torch.int32)
-            n = min(idx.numel(), t["cap"])
-            t["rows"].fill_(-1)
-            t["rows"][:n] = idx[:n]
-            t["count"][0] = n | (0x40000000 if idx.numel() > t["cap"] else 0)
-            t["touched"].zero_()
+    def _compact(self, t):
+        self.prims.rows_compact(t["touched"], t["cap"], t["rows"], t["count"])
 
-    @staticmethod
-    def _gather(t):
-        if t["g"].is_cuda:
-            from . import ops
-            ops.rows_gather(t["g"], t["rows"], t["count"], t["cap"], t["send"])
-        else:
-            n = int(t["count"][0]) & 0x3fffffff
-            t["send"].zero_()
-            t["send"][:n] = t["g"][t["rows"][:n].long()]
+    def _gather(self, t):
+        self.prims.rows_gather(t["g"], t["rows"], t["count"], t["cap"], t["send"])
 
-    @staticmethod
-    def _scatter(t, rows, count, src, add):
-        if t["g"].is_cuda:
-            from . import ops
-            ops.rows_scatter(t["g"], rows, count, t["cap"], src, add)
-        else:
-            n = int(count[0]) & 0x3fffffff
-            idx = rows[:n].long()
-            if src is None:
-                t["g"][idx] = 0
-            elif add:
-                t["g"][idx] += src[:n]
-            else:
-                t["g"][idx] = src[:n]
+    def _scatter(self, t, rows, count, src, add):
+        self.prims.rows_scatter(t["g"], rows, count, t["cap"], src, add)
 
     def exchange(self):
         """Call once per optimiser step, after the last backward (the touched flags accumulate over micro-batches)."""

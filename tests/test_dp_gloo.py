@@ -87,6 +87,37 @@ def test_reducer_is_noop_single_process():
     assert red.launched == [] and red.last_launched == []
 
 
+class TorchRowPrims:
+    """CPU stand-ins for the ego_rows_* kernels (same contracts: egom2p_hip.h), used ONLY to rehearse the collective
+    pattern of dp.SparseTableExchange over gloo; the kernels themselves are tested on the GPU (test_frontend_gpu.py)."""
+
+    @staticmethod
+    def rows_compact(touched, cap, rows, count):
+        idx = torch.nonzero(touched).flatten().to(torch.int32)
+        n = min(idx.numel(), cap)
+        rows.fill_(-1)
+        rows[:n] = idx[:n]
+        count[0] = n | (0x40000000 if idx.numel() > cap else 0)
+        touched.zero_()
+
+    @staticmethod
+    def rows_gather(table, rows, count, cap, out):
+        n = int(count[0]) & 0x3fffffff
+        out.zero_()
+        out[:n] = table[rows[:n].long()]
+
+    @staticmethod
+    def rows_scatter(table, rows, count, cap, src, add):
+        n = int(count[0]) & 0x3fffffff
+        idx = rows[:n].long()
+        if src is None:
+            table[idx] = 0
+        elif add:
+            table[idx] += src[:n]
+        else:
+            table[idx] = src[:n]
+
+
 def _sparse_worker(rank, world, port, ret):
     from egom2p_amd.dp import SparseTableExchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -107,7 +138,7 @@ def _sparse_worker(rank, world, port, ret):
     dense = [g.clone() for g, _ in tables]
     for d in dense:
         dist.all_reduce(d, op=dist.ReduceOp.SUM)
-    ex = SparseTableExchange(tables, cap_rows=cap)
+    ex = SparseTableExchange(tables, cap_rows=cap, prims=TorchRowPrims)
     assert ex.world == 2
     ex.exchange()
     assert not ex.overflowed()
@@ -120,7 +151,7 @@ def _sparse_worker(rank, world, port, ret):
     both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, chk)
     # a cap that is too small is reported, not silently truncated
-    tiny = SparseTableExchange([(torch.zeros(V, D), torch.ones(V, dtype=torch.uint8))], cap_rows=16)
+    tiny = SparseTableExchange([(torch.zeros(V, D), torch.ones(V, dtype=torch.uint8))], cap_rows=16, prims=TorchRowPrims)
     tiny.exchange()
     if rank == 0:
         ret["worst"] = worst
