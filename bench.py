@@ -98,6 +98,12 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its version block at
+    # communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from egom2p_amd import synth
     from egom2p_amd.config import MODEL_CFGS
     from egom2p_amd.engine import Engine
@@ -215,7 +221,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

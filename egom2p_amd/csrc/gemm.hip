@@ -471,6 +471,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                 __builtin_amdgcn_sched_barrier(0);                                         // keep the live set at one column group
             }
         }
+#ifdef NT_DIRECT_EPI
+        if constexpr (EK == 0) {
+            // register epilogue: lane (m = lane & 15, n = 4 (lane >> 4) .. +3) of every 16 x 16 block stores its 4 bf16 (8 B);
+            // the four lanes of a row make 32 contiguous bytes, the four j blocks of the wave complete the 128-byte line in L2
+            bf16_t* Cb = (bf16_t*)p.C + moff * p.ldc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gm = row0 + grp * 128 + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gn = col0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                    const f32x4 v = acc[i][j];
+                    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    if (gm < M && gn < p.N) *(u32x2*)(Cb + (long)gm * p.ldc + gn) = o;
+                }
+            }
+        } else
+#endif
         if constexpr (EK == 0) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
