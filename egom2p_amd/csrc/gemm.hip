@@ -306,11 +306,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
     // (piece j of a wave starts 8 rows after piece j - 1: one lane offset per operand, the rest goes into the scalar offset)
     unsigned a_off0, b_off0;
+#ifdef NT_SPEC
+    // wave-specialised variant (EK 0): the waves of group 1 issue every LDS-DMA (their own 32 tile rows and the 32 rows 128
+    // above), the waves of group 0 issue every global store - so no wave ever waits on vmcnt for its stores
+    constexpr bool SPEC = EK == 0 && !FP8;
+#else
+    constexpr bool SPEC = false;
+#endif
     {
-        const int r = 8 * (wave * 4) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
+        const int r = 8 * ((SPEC ? wave & 3 : wave) * 4) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
         a_off0 = (unsigned)(r * (int)p.lda * ESZ + c);
         b_off0 = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * ESZ + c);
     }
+    const unsigned a_half = (unsigned)(128 * (int)p.lda * ESZ), b_half = (unsigned)(128 * (int)p.ldb * ESZ);
     const unsigned a_step = (unsigned)(8 * (int)p.lda * ESZ), b_step = (unsigned)(8 * (int)p.ldb * ESZ);
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
@@ -344,6 +352,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
                                                  16, b_off0, (int)(b_so + j * b_step), 0, 0);
     };
+    // SPEC: the four pieces of tile-row half h (0: rows 0-127, 1: rows 128-255) that belong to wave & 3
+    auto dmaA4 = [&](int slot, int h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (h * 16 + (wave & 3) * 4 + j) * 1024),
+                                                     16, a_off0, (int)(a_so + h * a_half + j * a_step), 0, 0);
+    };
+    auto dmaB4 = [&](int slot, int h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (h * 16 + (wave & 3) * 4 + j) * 1024),
+                                                     16, b_off0, (int)(b_so + h * b_half + j * b_step), 0, 0);
+    };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
     int foff[2];
@@ -355,6 +376,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     int id = blockIdx.x, row0, col0;
     tile_origin(id, row0, col0);
     // prologue: A(0), B(0), then A(1); the first two must have landed
+    if constexpr (SPEC) {
+        cursorA();
+        if (grp == 1) { dmaA4(slotA, 0); dmaA4(slotA, 1); }
+        advanceA();
+        cursorB();
+        if (grp == 1) { dmaB4(slotB, 0); dmaB4(slotB, 1); }
+        advanceB();
+        if (moreA) {
+            cursorA();
+            if (grp == 1) { dmaA4(slotA, 0); dmaA4(slotA, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            advanceA();
+        } else if (grp == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
     cursorA();
 #pragma unroll
     for (int j = 0; j < 4; ++j) dmaA(slotA, j);
@@ -371,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
     bar_pinned();
     int curA = 0, curB = 0;                                   // ring slots of the K-tile about to be consumed
@@ -414,6 +451,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             const int sA = slotA, sB = slotB;
             if (fa) cursorA();
             if (fb) cursorB();
+            if constexpr (SPEC) {
+            // group 1 issues everything: B(g+1) in phases 0 / 1, A(g+2) in phases 2 / 3, and waits for B(g+1) and A(g+1)
+            LOAD_A(0) LOAD_B(0)
+            if (grp == 1 && fb) dmaB4(sB, 0);
+            bar_pinned();
+            COMPUTE(0, 0)
+            bar_pinned();
+            LOAD_B(1)
+            if (grp == 1 && fb) dmaB4(sB, 1);
+            bar_pinned();
+            COMPUTE(0, 1)
+            bar_pinned();
+            LOAD_A(1)
+            if (grp == 1 && fa) dmaA4(sA, 0);
+            bar_pinned();
+            COMPUTE(1, 1)
+            bar_pinned();
+            LOAD_B(0)
+            if (grp == 1) { if (fa) { dmaA4(sA, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            bar_pinned();
+            COMPUTE(1, 0)
+            bar_pinned();
+            } else {
             // ---- phase 0: quadrant (0,0)
             LOAD_A(0) LOAD_B(0)
             if (grp == 1 && fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
@@ -443,6 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             COMPUTE(1, 0)
             if (grp == 0) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
+            }
             if (fa) advanceA();
             if (fb) advanceB();
             curA = curA == 2 ? 0 : curA + 1;
@@ -517,6 +578,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                     }
                 }
                 lds_barrier();
+                if constexpr (SPEC) {
+                    if (grp == 0) {
+#pragma unroll
+                        for (int ps = 0; ps < 16; ++ps) {
+                            const int r = ps * 8 + (tid >> 5), c = tid & 31;
+                            const u32x4 v = *(const u32x4*)((ps < 8 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
+                            const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
+                            if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
+                        }
+                    }
+                } else
     #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
                     const int r = ps * 16 + (tid >> 5), c = tid & 31;
