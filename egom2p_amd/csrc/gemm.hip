@@ -306,19 +306,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     // wave instruction (wave*4 + j) fills tile rows 8(wave*4+j)..+7 (1 KiB), swizzle on the source
     // (piece j of a wave starts 8 rows after piece j - 1: one lane offset per operand, the rest goes into the scalar offset)
     unsigned a_off0, b_off0;
-#ifdef NT_SPEC
-    // wave-specialised variant (EK 0): the waves of group 1 issue every LDS-DMA (their own 32 tile rows and the 32 rows 128
-    // above), the waves of group 0 issue every global store - so no wave ever waits on vmcnt for its stores
-    constexpr bool SPEC = EK == 0 && !FP8;
-#else
-    constexpr bool SPEC = false;
-#endif
     {
-        const int r = 8 * ((SPEC ? wave & 3 : wave) * 4) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
+        const int r = 8 * (wave * 4) + (lane >> 3), c = ((lane & 7) ^ (r & 7)) * 16;
         a_off0 = (unsigned)(r * (int)p.lda * ESZ + c);
         b_off0 = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * ESZ + c);
     }
-    const unsigned a_half = (unsigned)(128 * (int)p.lda * ESZ), b_half = (unsigned)(128 * (int)p.ldb * ESZ);
     const unsigned a_step = (unsigned)(8 * (int)p.lda * ESZ), b_step = (unsigned)(8 * (int)p.ldb * ESZ);
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
@@ -352,19 +344,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
                                                  16, b_off0, (int)(b_so + j * b_step), 0, 0);
     };
-    // SPEC: the four pieces of tile-row half h (0: rows 0-127, 1: rows 128-255) that belong to wave & 3
-    auto dmaA4 = [&](int slot, int h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (h * 16 + (wave & 3) * 4 + j) * 1024),
-                                                     16, a_off0, (int)(a_so + h * a_half + j * a_step), 0, 0);
-    };
-    auto dmaB4 = [&](int slot, int h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (h * 16 + (wave & 3) * 4 + j) * 1024),
-                                                     16, b_off0, (int)(b_so + h * b_half + j * b_step), 0, 0);
-    };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
     int foff[2];
@@ -376,21 +355,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     int id = blockIdx.x, row0, col0;
     tile_origin(id, row0, col0);
     // prologue: A(0), B(0), then A(1); the first two must have landed
-    if constexpr (SPEC) {
-        cursorA();
-        if (grp == 1) { dmaA4(slotA, 0); dmaA4(slotA, 1); }
-        advanceA();
-        cursorB();
-        if (grp == 1) { dmaB4(slotB, 0); dmaB4(slotB, 1); }
-        advanceB();
-        if (moreA) {
-            cursorA();
-            if (grp == 1) { dmaA4(slotA, 0); dmaA4(slotA, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-            advanceA();
-        } else if (grp == 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    } else {
     cursorA();
 #pragma unroll
     for (int j = 0; j < 4; ++j) dmaA(slotA, j);
@@ -407,7 +371,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     }
     bar_pinned();
     int curA = 0, curB = 0;                                   // ring slots of the K-tile about to be consumed
@@ -451,29 +414,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             const int sA = slotA, sB = slotB;
             if (fa) cursorA();
             if (fb) cursorB();
-            if constexpr (SPEC) {
-            // group 1 issues everything: B(g+1) in phases 0 / 1, A(g+2) in phases 2 / 3, and waits for B(g+1) and A(g+1)
-            LOAD_A(0) LOAD_B(0)
-            if (grp == 1 && fb) dmaB4(sB, 0);
-            bar_pinned();
-            COMPUTE(0, 0)
-            bar_pinned();
-            LOAD_B(1)
-            if (grp == 1 && fb) dmaB4(sB, 1);
-            bar_pinned();
-            COMPUTE(0, 1)
-            bar_pinned();
-            LOAD_A(1)
-            if (grp == 1 && fa) dmaA4(sA, 0);
-            bar_pinned();
-            COMPUTE(1, 1)
-            bar_pinned();
-            LOAD_B(0)
-            if (grp == 1) { if (fa) { dmaA4(sA, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            bar_pinned();
-            COMPUTE(1, 0)
-            bar_pinned();
-            } else {
             // ---- phase 0: quadrant (0,0)
             LOAD_A(0) LOAD_B(0)
             if (grp == 1 && fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
@@ -503,7 +443,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             COMPUTE(1, 0)
             if (grp == 0) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
-            }
             if (fa) advanceA();
             if (fb) advanceB();
             curA = curA == 2 ? 0 : curA + 1;
@@ -532,34 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                 __builtin_amdgcn_sched_barrier(0);                                         // keep the live set at one column group
             }
         }
-#ifdef NT_DIRECT_EPI
-        if constexpr (EK == 0) {
-            // register epilogue: lane (m = lane & 15, n = 4 (lane >> 4) .. +3) of every 16 x 16 block stores its 4 bf16 (8 B);
-            // the four lanes of a row make 32 contiguous bytes, the four j blocks of the wave complete the 128-byte line in L2
-            bf16_t* Cb = (bf16_t*)p.C + moff * p.ldc;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gm = row0 + grp * 128 + i * 16 + (lane & 15);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int gn = col0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-                    const f32x4 v = acc[i][j];
-                    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    if (gm < M && gn < p.N) *(u32x2*)(Cb + (long)gm * p.ldc + gn) = o;
-                }
-            }
-        } else
-#endif
-#if defined(NT_ABL) && NT_ABL == 2
-        if constexpr (EK == 0) {                       // timing-only ablation: no epilogue at all (keeps the accumulators alive)
-            f32x4 t = acc[0][0];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (i + j) t = t + acc[i][j];
-            if (t[0] + t[1] == 123.456f && t[2] + t[3] == 1.f) ((float*)p.C)[0] = t[1];
-        } else
-#endif
         if constexpr (EK == 0) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -578,29 +489,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
                     }
                 }
                 lds_barrier();
-                if constexpr (SPEC) {
-                    if (grp == 0) {
-#pragma unroll
-                        for (int ps = 0; ps < 16; ++ps) {
-                            const int r = ps * 8 + (tid >> 5), c = tid & 31;
-                            const u32x4 v = *(const u32x4*)((ps < 8 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
-                            const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
-                            if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
-                        }
-                    }
-                } else
     #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
                     const int r = ps * 16 + (tid >> 5), c = tid & 31;
                     const u32x4 v = *(const u32x4*)((ps < 4 ? ea : ebb) + (r & 63) * 512 + ((c ^ (r & 15)) << 4));
                     const int gm = row0 + half * 128 + r, gn = col0 + c * 8;
-#if defined(NT_ABL) && NT_ABL == 1
-                    if (gm < M && gn < p.N && v[0] == 0x12345678u) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
-#elif defined(NT_ABL) && NT_ABL == 3
-                    if (gm < M && gn < p.N) *(u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn) = v;
-#else
                     if (gm < M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
-#endif
                 }
                 lds_barrier();
             }
@@ -799,137 +693,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
 #undef LOAD_A
 #undef LOAD_B
 #undef COMPUTE
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT kernel, 256 x 128 tile, TWO workgroups per CU (experiment for hiding the epilogues: while one workgroup transposes
-// and stores its tile the other one owns the MFMA pipes).  4 waves (2 x 2), 128 x 64 per wave - the LDS read intensity
-// of the 256 x 256 kernel - K-tiles of 32 (64-byte LDS rows), three 24 KiB stages (72 KiB), K-tile g+2 in flight under
-// K-tile g, one barrier per K-step.  No pipeline across tiles: the other workgroup covers the seam, provided the two are
-// out of phase - the workgroups of the second dispatch round (blockIdx >= 256) start `stagger` 10-ns ticks late.
-// ---------------------------------------------------------------------------------------------
-constexpr int N2_ASTG = 256 * 64;                  // A stage: 256 rows x 32 bf16
-constexpr int N2_BSTG = 128 * 64;                  // B stage: 128 rows x 32 bf16
-constexpr int N2_STG = N2_ASTG + N2_BSTG;          // 24 KiB
-constexpr int N2_LDS = 3 * N2_STG;                 // 72 KiB
-#ifndef NT2_STAG
-#define NT2_STAG 0
-#endif
-
-template <int EK>
-__global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NTArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 1, wc = wave & 1;
-
-    int M = p.M;
-    long moff = 0;
-    if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
-    if (M <= 0) return;
-    const int tiles_n = (p.N + 127) / 128;
-    const int ntiles = ((M + 255) / 256) * tiles_n;
-    if ((int)blockIdx.x >= ntiles) return;
-    const int nt = p.K / 32;
-    const int G = gridDim.x;
-    if (NT2_STAG > 0 && blockIdx.x >= 256) {
-        const unsigned long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long wait = (unsigned long)p.K * NT2_STAG / 1000;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-
-    auto a_rsrc = [&](int row0) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (moff + row0) * p.lda * 2), 0,
-                                                 (int)(unsigned)((long)(min(256, M - row0) - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.B, 0, (int)(unsigned)((long)(p.N - 1) * p.ldb * 2 + (long)p.K * 2), 0x00020000);
-    // one DMA instruction = 16 tile rows x 64 B: lane l -> row l >> 2, slot l & 3 holding source chunk slot ^ ((row >> 2) & 3)
-    const int rl = lane >> 2, cl = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    const unsigned a_off0 = (unsigned)((wave * 64 + rl) * (int)p.lda * 2 + cl);
-    const unsigned b_off0 = (unsigned)((wave * 32 + rl) * (int)p.ldb * 2 + cl);
-    const unsigned a_step = (unsigned)(16 * (int)p.lda * 2), b_step = (unsigned)(16 * (int)p.ldb * 2);
-    // fragment offset inside an operand stage: row = 16 b + (lane & 15), k-chunk lane >> 4
-    const int foff = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
-    const int a_base = grp * 128 * 64 + foff, b_base = N2_ASTG + wc * 64 * 64 + foff;
-
-    for (int id = blockIdx.x; id < ntiles; id += G) {
-        const int t = xcd_remap(id, ntiles);
-        const int row0 = (t / tiles_n) * 256, col0 = (t % tiles_n) * 128;
-        const __amdgpu_buffer_rsrc_t ars = a_rsrc(row0);
-        const unsigned b_tile = (unsigned)col0 * (unsigned)(p.ldb * 2);
-        auto dma = [&](int kt, int stg) {
-            char* st = smem + stg * N2_STG;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(st + (wave * 4 + j) * 1024), 16, a_off0,
-                                                         (int)(kt * 64 + j * a_step), 0, 0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(st + N2_ASTG + (wave * 2 + j) * 1024), 16,
-                                                         b_off0, (int)(b_tile + kt * 64 + j * b_step), 0, 0);
-        };
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dma(0, 0);
-        dma(1, 1);
-        int cur = 0, nxt = 2;
-        for (int kt = 0; kt < nt; ++kt) {
-            if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar_pinned();
-            if (kt + 2 < nt) dma(kt + 2, nxt);
-            const char* st = smem + cur * N2_STG;
-            bf16x8 af[8], bq[4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bq[ni] = *(const bf16x8*)(st + b_base + ni * 1024);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) af[mi] = *(const bf16x8*)(st + a_base + mi * 1024);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
-        }
-        // epilogue: the whole 256 x 128 bf16 tile (64 KiB) through LDS, [row][256 B], 16-byte chunk c of row r at c ^ (r & 15)
-        lds_barrier();
-        if constexpr (EK == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ml = grp * 128 + i * 16 + (lane & 15);
-                char* eb = smem + ml * 256;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int slot = wc * 16 + j * 4 + (lane >> 4);                  // 8-byte slot (4 bf16) in the row
-                    const f32x4 v = acc[i][j];
-                    const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2*)(eb + (((slot >> 1) ^ (ml & 15)) << 4) + (slot & 1) * 8) = o;
-                }
-            }
-            lds_barrier();
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                u32x4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = (hb * 8 + k) * 16 + (tid >> 4), c = tid & 15;
-                    v[k] = *(const u32x4*)(smem + r * 256 + ((c ^ (r & 15)) << 4));
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int gm = row0 + (hb * 8 + k) * 16 + (tid >> 4), gn = col0 + (tid & 15) * 8;
-                    if (gm < M && gn < p.N) __builtin_nontemporal_store(v[k], (u32x4*)((bf16_t*)p.C + (moff + gm) * p.ldc + gn));
-                }
-            }
-            lds_barrier();
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,7 +1098,6 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS);
     g_attr_done = true;
 }
 
@@ -1372,14 +1134,6 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     // residual epilogue stay on the 128x128 kernel (two workgroups per CU hide each other's epilogue).
     const bool legal256 = N % 128 == 0 && K >= 2 * BK && 256L * lda * 2 < 0x7ff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
-#ifdef NT2
-    if (big && epi == EGO_EPI_BF16) {
-        const int tiles2 = ((M + 255) / 256) * ((N + 127) / 128);
-        EGO_LAUNCH(gemm_nt2_kernel<0>, dim3(tiles2 < 512 ? tiles2 : 512), dim3(256), N2_LDS, stream, a);
-        LAUNCH_CHECK();
-        return EGO_OK;
-    }
-#endif
     if (big) {
         if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
         else { EGO_LAUNCH(gemm_nt256_kernel<1>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
