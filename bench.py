@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="egom2p_base_12e_12d_swiglu_nobias")
     ap.add_argument("--clips-per-gpu", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64,
+                    help="clips per forward/backward (accumulated to --clips-per-gpu); 64 measured best on MI355X: 32 -1.5 %, 128 -0.6 %")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["quick", "full", "full-fp32", "full-bf16"], default="quick",
                     help="quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; full: SURVEY 8(d) protocol (~15 min)")
@@ -202,9 +203,11 @@ def main():
             pmc = json.load(open(pmc_path))
             ent = pmc.get("abi", {}).get(dom[0])
             same = pmc.get("kernel_src_sha") == kernel_source_sha()
-            if ent and same and pmc.get("micro_batch") == args.micro_batch and args.model == "egom2p_base_12e_12d_swiglu_nobias":
+            if ent and same and pmc.get("micro_batch") == mb and args.model == "egom2p_base_12e_12d_swiglu_nobias":
                 out["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/pmc_latest.json)"
+            elif ent and same:
+                out["roofline"]["traffic_note"] = f"profiles/pmc_latest.json holds micro-batch {pmc.get('micro_batch')}, this run {mb}"
             elif ent and not same:
                 out["roofline"]["traffic_note"] = ("profiles/pmc_latest.json was measured on other kernel sources "
                                                    f"({pmc.get('kernel_src_sha')} vs {kernel_source_sha()}): re-run tools/pmc_run.sh")

@@ -200,6 +200,49 @@ def test_full_size_step_agrees_across_kernel_families():
         assert d < 1e-2, (lo, hi, d)
 
 
+def test_micro_batch_64_equals_two_accumulated_halves():
+    """bench.py's default micro-batch (64 clips = 131072 rows per side, logits of 64576 x 64000 = 4.1e9 elements per video
+    modality: beyond 2^31) cannot be followed by the oracle; the size-independent property is linearity of the step in the
+    batch: one forward / backward over 64 canonical clips equals the accumulation of its two 32-clip halves (the regime the
+    reference fixtures and the test above validate) - same loss, same per-modality losses, same gradients up to fp32
+    summation order."""
+    cfg = MODEL_CFGS["egom2p_base_12e_12d_swiglu_nobias"]
+    B = 64
+    eng = Engine(cfg, "cuda:0", max_batch=B, n_enc=2048, n_dec=2048)
+    eng.init_random(5)
+    md = synth.make_clip_batch_device(cfg, B, synth.CANONICAL_BUDGETS, seed=9, sample_offset=0, device="cuda:0")
+    order = [m.name for m in cfg.mods]
+    eng.zero_grad()
+    loss, mod_loss = eng.forward(md, dec_order=order)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    l64, m64, g64 = float(loss), {k: float(v) for k, v in mod_loss.items()}, eng.G.clone()
+    eng.zero_grad()
+    lh, mh = 0.0, {k: 0.0 for k in m64}
+    for half in range(2):
+        part = {k: {kk: vv[half * 32:(half + 1) * 32].contiguous() for kk, vv in v.items()} for k, v in md.items()}
+        loss, mod_loss = eng.forward(part, dec_order=order)
+        eng.backward(0.5)
+        lh += 0.5 * float(loss)
+        for k, v in mod_loss.items():
+            mh[k] += 0.5 * float(v)
+    torch.cuda.synchronize()
+    assert np.isfinite(l64) and abs(l64 - lh) <= 2e-5 * abs(lh), (l64, lh)
+    for k in m64:
+        assert abs(m64[k] - mh[k]) <= 5e-5 * abs(mh[k]), (k, m64[k], mh[k])
+    g32 = eng.G
+    assert torch.isfinite(g64).all()
+    rel = float((g64 - g32).double().norm() / g32.double().norm())
+    assert rel < 3e-3, rel
+    n = g32.numel()
+    for lo in range(0, n, n // 16):
+        hi = min(n, lo + n // 16)
+        d = float((g64[lo:hi] - g32[lo:hi]).double().norm() / max(float(g32[lo:hi].double().norm()), 1e-30))
+        assert d < 1e-2, (lo, hi, d)
+    del eng, g64
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", ["b2", "L2"])
 def test_fp8_forward_stays_within_stated_tolerance(case):
     """BASELINE config 5 ("bf16 + fp8 MFMA GEMMs"): the forward linears on e4m3 operands (per-row activation scales,

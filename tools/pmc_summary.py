@@ -57,9 +57,9 @@ def main():
         abi[entry] = {"launches": n, "traffic_bytes_per_launch": tot / n}
     meta = {"note": "HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE doubled "
                     "per the gfx950 correction (MI355X_MICROARCH.md, HBM); counter units KiB -> bytes",
-            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --clips-per-gpu 32 --steps 1 "
+            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --clips-per-gpu MB --micro-batch MB --steps 1 "
                        "--warmup 0 --no-cpu-baseline --no-kernel-profile",
-            "micro_batch": 32, "kernel_src_sha": kernel_source_sha(), "kernels": out, "abi": abi}
+            "micro_batch": int(os.environ.get("EGOM2P_PMC_MICRO_BATCH", "64")), "kernel_src_sha": kernel_source_sha(), "kernels": out, "abi": abi}
     json.dump(meta, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
