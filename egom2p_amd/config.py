@@ -37,6 +37,11 @@ TOK_CAM = Modality("tok_cam", 256, 30, "seq1d", "cam")
 TOK_GAZE = Modality("tok_gaze", 256, 30, "seq1d", "gaze")
 
 MODALITIES: Dict[str, Modality] = {m.name: m for m in (TOK_RGB, TOK_DEPTH, TOK_CAM, TOK_GAZE)}
+# Build-owned parity-test modalities: six more 30-token sequence modalities of the cam / gaze embedding class
+# (`GazeCamToken{Encoder,Decoder}Embedding`), so that a model with EGO_MAX_MODS = 8 modalities can be pinned against
+# the reference (tests/golden/tiny8.npz).
+for _i in range(6):
+    MODALITIES[f"tok_aux{_i}"] = Modality(f"tok_aux{_i}", 256, 30, "seq1d", "cam" if _i % 2 == 0 else "gaze")
 
 
 @dataclass(frozen=True)
@@ -79,6 +84,9 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     "egom2p_large_24e_24d_swiglu_nobias": ModelCfg("egom2p_large_24e_24d_swiglu_nobias", 1020, 24, 24, 15),
     # build-owned
     "ego_tiny_2e_2d": ModelCfg("ego_tiny_2e_2d", 128, 2, 2, 2, modalities=("tok_cam", "tok_gaze")),
+    # eight modalities (the C-ABI's EGO_MAX_MODS) at plumbing size
+    "ego_tiny8_2e_2d": ModelCfg("ego_tiny8_2e_2d", 128, 2, 2, 2,
+                                modalities=("tok_cam", "tok_gaze") + tuple(f"tok_aux{i}" for i in range(6))),
     "ego_b_2e_2d": ModelCfg("ego_b_2e_2d", 768, 2, 2, 12),
     # untied decoder head (`share_embedding=False`, the FM wrapper's setting: egom2p_model.py:856-858) at parity-test depth
     "ego_b_2e_2d_untied": ModelCfg("ego_b_2e_2d_untied", 768, 2, 2, 12, share_embedding=False),

@@ -251,6 +251,11 @@ CASES = {
     "tiny_pad": dict(cfg_name="ego_tiny_2e_2d", batch=4, n_enc=32, n_dec=32,
                      budgets={"tok_cam": [(10, 12), (3, 0), (15, 15), (0, 7)],
                               "tok_gaze": [(9, 5), (20, 10), (1, 29), (16, 0)]}, seed=2, full_float=True, py_seed=12),
+    # eight modalities (EGO_MAX_MODS), ragged budgets incl. clips without inputs / without targets in a modality
+    "tiny8": dict(cfg_name="ego_tiny8_2e_2d", batch=3, n_enc=64, n_dec=48,
+                  budgets={n: ([(4, 0), (0, 6), (3, 3)] if n == "tok_aux3" else [(5 + (b + j) % 7, 3 + (2 * b + j) % 5) for b in range(3)])
+                           for j, n in enumerate(("tok_cam", "tok_gaze") + tuple(f"tok_aux{i}" for i in range(6)))},
+                  seed=8, full_float=True, py_seed=18),
     # ego-b width, 2+2 layers, canonical split, N=M=2048
     "b2": dict(cfg_name="ego_b_2e_2d", batch=2, n_enc=2048, n_dec=2048, budgets=None, seed=3,
                full_float=False, py_seed=13),

@@ -43,7 +43,7 @@ def _tap(g, key, t):
     return max(e1, e2, e3)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "b2", "b2_ragged", "b2_untied", "b12", "L2"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim

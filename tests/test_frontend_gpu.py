@@ -39,6 +39,8 @@ def _run_compact(cfg, md, mods, n_keep, is_decoder):
 
 @pytest.mark.parametrize("cfg_name,B,n,budgets", [
     ("ego_tiny_2e_2d", 4, 32, {"tok_cam": [(10, 12), (3, 0), (15, 15), (0, 7)], "tok_gaze": [(9, 5), (20, 10), (1, 29), (16, 0)]}),
+    ("ego_tiny8_2e_2d", 3, 64, {n: ([(4, 0), (0, 6), (3, 3)] if n == "tok_aux3" else [(5 + (b + j) % 7, 3 + (2 * b + j) % 5) for b in range(3)])
+                                for j, n in enumerate(("tok_cam", "tok_gaze") + tuple(f"tok_aux{i}" for i in range(6)))}),   # EGO_MAX_MODS modalities
     ("ego_b_2e_2d", 3, 2048, None),
     ("ego_b_2e_2d", 4, 2048, "dirichlet"),
     ("ego_b_2e_2d", 2, 700, None),          # truncation: more valid tokens than kept
