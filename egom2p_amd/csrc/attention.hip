@@ -188,7 +188,9 @@ __device__ __forceinline__ void store_rows_bf16_hilo(bf16_t* hi, bf16_t* lo, con
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FWD_STAGES = 3;
+constexpr float FWD_TAU = 8.f;      // the softmax reference moves when a score exceeds it by more than this (exp2 domain)
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,9 +214,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
+    // Q is pre-scaled by scale * log2(e) (as in the backward kernels), so the scores leave the MFMA in the exp2 domain
     bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 qr = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qr[e] * sc);
+    }
 
     const bf16_t* Kb = p.K + (long)b * p.k_bs + h * 64;
     const bf16_t* Vb = p.V + (long)b * p.v_bs + h * 64;
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
     float m = NEG_BIG, l = 0.f;
+    bool seeded = false;                 // every lane of the wave has a finite reference m
     const TrAddr tra = tr_addr((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem, lane);
 
     // K / V ring of FWD_STAGES tiles, filled two tiles ahead; every tile is 4 DMA instructions of this wave, so
@@ -248,20 +256,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
 
+        // Online softmax with a LAZY reference: `m` is the value subtracted from the scores, not necessarily their running
+        // maximum.  On a tile that lies inside every lane's interval, once every lane has a finite reference, -m is the
+        // INITIAL accumulator of the S^T chain (the subtraction is free) and p = exp2(acc) directly; the reference only moves
+        // when some score exceeds it by more than FWD_TAU (p <= 2^FWD_TAU, far from any overflow) - after the first tiles
+        // that is rare.  This kernel is VALU-bound at head dim 64: 32 exp + ~48 other vector instructions per 16 MFMAs.
+        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        const bool fast = full && seeded;
+        const float ini = fast ? -m : 0.f;
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+            for (int i = 0; i < 16; ++i) st[kb][i] = ini;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb, s, lane), qf[s], st[kb], 0, 0, 0);
         }
         s16x4 va[4][2], vb[4][2];
         tr_issue<TILE_BYTES, 0>(tra, s_ * 2 * TILE_BYTES, va);
-        // online softmax in the raw-score domain: p = exp2(s * sc - m * sc) is ONE fma + one v_exp per element
-        // (this kernel is VALU-bound at head_dim 64); `m` tracks the running max of the raw scores (sc >= 0).
-        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
         float mx = NEG_BIG;
         if (full) {
 #pragma unroll
@@ -280,37 +293,42 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
                 }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        // the running max of most rows stops moving after the first tiles: skip the 32-register O rescale then
-        if (__any(mnew > m)) {
-            const float alpha = __builtin_amdgcn_exp2f((m - mnew) * sc);
-            l *= alpha;
+        if (fast) {
+            // scores are relative to m already; move the reference only where they outgrow it
+            if (__any(mx > FWD_TAU)) {
+                const float d = fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                m += d;
+                l *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
-        }
-        m = mnew;
-        const float msc = mnew * sc;
-        float rs = 0.f;
-        if (full) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -msc));
-                    rs += pv;
-                    st[kb][r] = pv;
-                }
+                for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; st[0][i] -= d; st[1][i] -= d; }
+            }
         } else {
+            const float mnew = fmaxf(m, mx);
+            if (__any(mnew > m)) {
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+            }
+            m = mnew;
+            // masked scores (and rows that have seen no key yet) must give p = 0: exp2(-1e30) = 0
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = (st[kb][r] <= NEG_BIG) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], sc, -msc));
-                    rs += pv;
-                    st[kb][r] = pv;
-                }
+                for (int r = 0; r < 16; ++r) st[kb][r] = (st[kb][r] <= NEG_BIG) ? NEG_BIG : st[kb][r] - mnew;
+            seeded = __all(m > NEG_BIG);
         }
-        l += rs;
+        f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 pv = {__builtin_amdgcn_exp2f(st[kb][r]), __builtin_amdgcn_exp2f(st[kb][r + 1])};
+                rs2 += pv;
+                st[kb][r] = pv[0]; st[kb][r + 1] = pv[1];
+            }
+        l += rs2[0] + rs2[1];
         // O^T += V^T P^T: V fragments by asm transposed reads (k-steps 0,1 were started before the softmax)
         tr_issue<TILE_BYTES, 2>(tra, s_ * 2 * TILE_BYTES, vb);
         lgkm_wait_tied<8>(va);
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
         const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
         if (p.Olo) store_rows_bf16_hilo(p.O + oo, p.Olo + oo, ot, inv, hh);
         else store_rows_bf16(p.O + oo, ot, inv, hh);
-        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = -(m * sc + __builtin_amdgcn_logf(lt));  // v_log_f32 = log2; stored NEGATED
+        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = -(m + __builtin_amdgcn_logf(lt));  // v_log_f32 = log2; stored NEGATED
     }
 }
 
