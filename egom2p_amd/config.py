@@ -7,7 +7,7 @@ Mirrors the information the reference keeps in `egom2p/data/modality_info.py:59-
 from __future__ import annotations
 
 import hashlib
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
 

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import copy
 import math
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import numpy as np
 import torch

@@ -14,14 +14,14 @@ from __future__ import annotations
 
 import random
 from functools import partial
-from typing import Any, Callable, Dict, List, Optional
+from typing import Any, Callable, Dict, Optional
 
 import torch
 from torch import nn
 
 from . import _lib as L
-from . import ops
-from .config import MODALITIES, Modality, ModelCfg, uint15_hash
+from . import ops  # noqa: F401  (importing it fails loudly when the HIP library is missing: no CPU path)
+from .config import MODALITIES, Modality, ModelCfg
 from .engine import Engine
 
 __all__ = ["EgoM2P", "LayerNorm", "create_model", "register_model", "list_models", "model_entrypoint",

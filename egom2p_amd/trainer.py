@@ -7,7 +7,7 @@ Mirrors the body of `train_one_epoch` (run_training_egom2p.py:701-746) without i
 from __future__ import annotations
 
 import random
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 
