@@ -7,7 +7,7 @@ come from the counter-based generator.  Per schedule step the fixture holds the 
 statistics of the conditional / unconditional logits, and the tokens the reference sampled (teacher forcing
 for the next step).
 
-    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768]
+    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768 | gen_rgb2cam_b768 | gen_rgb2gaze_b768 | gen_depth2rgb_b768]
 """
 from __future__ import annotations
 
@@ -47,37 +47,47 @@ def main():
     G = _load("egom2p.models.generate", "egom2p/models/generate.py")
 
     which = sys.argv[1] if len(sys.argv) > 1 else "gen_rgb2depth"
-    # gen_rgb2depth: D = 384 plumbing case.  gen_rgb2depth_b768: ego-b width (D = 768, 12 heads) with a PEAKED depth head
-    # (synth.peak_logit_table), so that the sampled tokens themselves can be compared
-    cfg_name, seed, peaked = {"gen_rgb2depth": ("ego_gen_384_2e_2d", 21, False),
-                              "gen_rgb2depth_b768": ("ego_b_gen_2e_2d", 22, True)}[which]
+    # gen_rgb2depth: D = 384 plumbing case.  The *_b768 cases: ego-b width (D = 768, 12 heads) with a PEAKED target head
+    # (synth.peak_logit_table), so that the sampled tokens themselves can be compared.  The four tasks are the reference's four
+    # eval scripts (eval_model_{rgb2depth,rgb2cam,rgb2gaze,depth2rgb}.py: ROAR, linear schedule, T = 0.01, CFG 2.0, top-p 0.8)
+    TASKS = {  # name: (cfg, seed, peaked, cond, target, tokens, decoding steps)
+        "gen_rgb2depth": ("ego_gen_384_2e_2d", 21, False, "tok_rgb", "tok_depth", 5120, 3),
+        "gen_rgb2depth_b768": ("ego_b_gen_2e_2d", 22, True, "tok_rgb", "tok_depth", 5120, 3),
+        "gen_rgb2cam_b768": ("ego_b_2e_2d", 23, True, "tok_rgb", "tok_cam", 30, 3),          # eval_model_rgb2cam.py:46-60
+        "gen_rgb2gaze_b768": ("ego_b_2e_2d", 24, True, "tok_rgb", "tok_gaze", 30, 5),        # eval_model_rgb2gaze.py:47-61
+        "gen_depth2rgb_b768": ("ego_b_2e_2d", 25, True, "tok_depth", "tok_rgb", 5120, 6),    # eval_model_depth2rgb.py:40-54
+    }
+    cfg_name, seed, peaked, cond, target_mod, n_target, n_steps = TASKS[which]
     cfg = MODEL_CFGS[cfg_name]
     torch.set_num_threads(8)
     torch.set_grad_enabled(False)
     net = MG.build_reference_model(cfg, enc, dec, model)
     sd = synth.build_state_dict(cfg, seed)
     if peaked:
-        synth.peak_logit_table(sd, "tok_depth", seed)
+        synth.peak_logit_table(sd, target_mod, seed)
     net.load_state_dict(sd, strict=True)
     net.eval()
     sampler = G.GenerationSampler(net)
     info = net.modality_info
 
+    # conditioning clip: the reference's own data file (real Cosmos ids of an rgb clip; for depth2rgb the same ids stand in
+    # for depth tokens - the reference's depth example is an mp4 that needs the external Cosmos tokenizer)
     rgb = np.load(os.path.join(REF, "example_data", "rgb2cam_egoexo.npz"))
     key = [k for k in rgb.files][0]
     ids = np.asarray(rgb[key]).astype(np.int64).reshape(1, 5, 32, 32)
-    sample = {"tok_rgb": {"tensor": torch.from_numpy(ids), "input_mask": torch.zeros(1, 5120, dtype=torch.bool),
-                          "target_mask": torch.ones(1, 5120, dtype=torch.bool)}}
-    sample = G.init_empty_target_modality(sample, info, "tok_depth", 1, 5120, "cpu")
-    sample = G.init_full_input_modality(sample, info, "tok_rgb", "cpu")
+    sample = {cond: {"tensor": torch.from_numpy(ids), "input_mask": torch.zeros(1, 5120, dtype=torch.bool),
+                     "target_mask": torch.ones(1, 5120, dtype=torch.bool)}}
+    sample = G.init_empty_target_modality(sample, info, target_mod, 1, n_target, "cpu")
+    sample = G.init_full_input_modality(sample, info, cond, "cpu")
     schedule = G.build_chained_generation_schedules(
-        cond_domains=["tok_rgb"], target_domains=["tok_depth"], tokens_per_target=[5120], autoregression_schemes=["roar"],
-        decoding_steps=[3], token_decoding_schedules=["linear"], temps=[0.01], temp_schedules=["constant"],
+        cond_domains=[cond], target_domains=[target_mod], tokens_per_target=[n_target], autoregression_schemes=["roar"],
+        decoding_steps=[n_steps], token_decoding_schedules=["linear"], temps=[0.01], temp_schedules=["constant"],
         cfg_scales=[2.0], cfg_schedules=["constant"], cfg_grow_conditioning=True)
     top_p, top_k, gseed = 0.8, 0.0, 0
 
     gold = {"rgb_ids": ids.astype(np.int32), "n_steps": np.array(len(schedule)),
-            "meta": np.array(repr(dict(cfg=cfg_name, seed=seed, top_p=top_p, gen_seed=gseed, peaked=peaked)))}
+            "meta": np.array(repr(dict(cfg=cfg_name, seed=seed, top_p=top_p, gen_seed=gseed, peaked=peaked, cond=cond, target=target_mod,
+                                       tokens=n_target, steps=n_steps)))}
     mod_dict = copy.deepcopy(sample)
     for step, sinfo in enumerate(schedule):
         target, num_select, temp, cfg_scale = sinfo["target_domain"], sinfo["num_tokens"], sinfo["temperature"], sinfo["cfg_scale"]
@@ -101,12 +111,12 @@ def main():
         gold[f"s{step}.mod_pos"] = mod_pos.numpy().astype(np.int32)
         gold[f"s{step}.samples"] = samples.numpy().astype(np.int32)
         gold[f"s{step}.cfg"] = np.array([num_select, temp, cfg_scale])
-        gold[f"s{step}.n_enc"] = np.array([int((~mod_dict[m]["input_mask"]).sum()) for m in ("tok_rgb", "tok_depth")])
+        gold[f"s{step}.n_enc"] = np.array([int((~mod_dict[m]["input_mask"]).sum()) for m in (cond, target_mod)])
         mod_dict[target]["tensor"] = torch.scatter(mod_dict[target]["tensor"], -1, mod_pos, samples)
         mod_dict[target]["input_mask"] = torch.scatter(mod_dict[target]["input_mask"], -1, mod_pos, torch.zeros_like(samples, dtype=torch.bool))
         mod_dict[target]["target_mask"] = torch.scatter(mod_dict[target]["target_mask"], -1, mod_pos, torch.ones_like(samples, dtype=torch.bool))
         print(f"[goldens] step {step}: select {num_select}, enc tokens cond {gold[f's{step}.n_enc'].sum()}", flush=True)
-    gold["final_tokens"] = mod_dict["tok_depth"]["tensor"].numpy().astype(np.int32)
+    gold["final_tokens"] = mod_dict[target_mod]["tensor"].numpy().astype(np.int32)
     # schedule check values
     gold["schedule_tokens"] = np.array([s["num_tokens"] for s in schedule])
     path = os.path.join(ROOT, "tests", "golden", f"{which}.npz")

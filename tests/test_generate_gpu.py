@@ -81,30 +81,32 @@ def test_schedule_matches_reference():
     assert all(s["cfg_cond_domains"] == ["tok_rgb"] and s["cfg_scale"] == 2.0 and s["temperature"] == 0.01 for s in sch)
 
 
-@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768"])
+@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768", "gen_rgb2cam_b768", "gen_rgb2gaze_b768", "gen_depth2rgb_b768"])
 def test_roar_cfg_generation_matches_reference(fixture):
     """gen_rgb2depth: D = 384 with a random-init (flat) head - near-ties decide most tokens, so the bars are on the logits.
-    gen_rgb2depth_b768: ego-b width (D = 768, 12 heads, N up to 8534) with a PEAKED depth head (synth.peak_logit_table):
-    arg-max and sampled tokens must agree with the reference's on >= 99 % of the rows."""
+    The *_b768 fixtures: ego-b width (D = 768, 12 heads) with a PEAKED target head (synth.peak_logit_table): arg-max and sampled
+    tokens must agree with the reference's on >= 99 % of the rows.  They cover the reference's four generation scripts
+    (rgb -> depth 3 steps, rgb -> cam 3 steps, rgb -> gaze 5 steps, depth -> rgb 6 steps; N up to 9386 encoder tokens)."""
     g, meta = load_golden(fixture)
     cfg = MODEL_CFGS[meta["cfg"]]
     peaked = bool(meta.get("peaked", False))
+    cond, target, n_target = meta.get("cond", "tok_rgb"), meta.get("target", "tok_depth"), int(meta.get("tokens", 5120))
     eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=64, n_dec=64)
     sd = synth.build_state_dict(cfg, meta["seed"])
     if peaked:
-        synth.peak_logit_table(sd, "tok_depth", meta["seed"])
+        synth.peak_logit_table(sd, target, meta["seed"])
     eng.load_state_dict(sd)
     sampler = GenerationSampler(eng)
-    sample = {"tok_rgb": {"tensor": torch.from_numpy(g["rgb_ids"].astype(np.int64)).to(DEV)}}
-    sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 1, 5120, DEV)
-    sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+    sample = {cond: {"tensor": torch.from_numpy(g["rgb_ids"].astype(np.int64)).to(DEV)}}
+    sample = init_empty_target_modality(sample, MODALITY_INFO, target, 1, n_target, DEV)
+    sample = init_full_input_modality(sample, MODALITY_INFO, cond, DEV)
     md = sample
     agree_total, n_total = 0, 0
     for step in range(int(g["n_steps"])):
         num_select, temp, cfg_scale = g[f"s{step}.cfg"]
         mod_pos = torch.from_numpy(g[f"s{step}.mod_pos"].astype(np.int64)).to(DEV)
         forced = torch.from_numpy(g[f"s{step}.samples"].astype(np.int64)).to(DEV)
-        md, info = sampler.roar_step(md, "tok_depth", int(num_select), float(temp), 0.0, meta["top_p"], conditioning=["tok_rgb"],
+        md, info = sampler.roar_step(md, target, int(num_select), float(temp), 0.0, meta["top_p"], conditioning=[cond],
                                      guidance_scale=float(cfg_scale), mod_pos=mod_pos, return_logits=True, forced_samples=forced)
         for nm, lg in (("cond", info["logits_cond"]), ("uncond", info["logits_uncond"])):
             lg = lg[0].float()
@@ -112,8 +114,18 @@ def test_roar_cfg_generation_matches_reference(fixture):
             assert rel_l2(lg.norm(dim=-1).cpu().numpy(), g[f"s{step}.{nm}.rownorm"]) < 1e-2, (step, nm)
             lse_scale = max(1.0, float(np.abs(g[f"s{step}.{nm}.max"]).max()))          # peaked heads have logits in the hundreds
             assert np.abs(torch.logsumexp(lg, -1).cpu().numpy() - g[f"s{step}.{nm}.lse"]).max() < 5e-2 * lse_scale, (step, nm)
-            am = (lg.argmax(-1).cpu().numpy() == g[f"s{step}.{nm}.argmax"]).mean()
-            assert am > (0.99 if peaked else 0.9), (step, nm, am)
+            ref_am = torch.from_numpy(g[f"s{step}.{nm}.argmax"].astype(np.int64)).to(DEV)
+            mism = lg.argmax(-1) != ref_am
+            am = 1.0 - mism.float().mean().item()
+            if mism.any():       # a differing arg-max must be explained by the logit error this test accepts above (3e-2 relative):
+                # in OUR logits the reference's token is within 3e-2 x the row's largest |logit| of the row maximum (the peaked
+                # table rows have norms up to 1000x: a logit that is small by cancellation still carries the noise of its terms)
+                top = lg.max(-1).values
+                gap = (top - lg.gather(1, ref_am[:, None])[:, 0])[mism]
+                tol = torch.clamp(3e-2 * lg.abs().max(-1).values[mism], min=0.35)
+                assert bool((gap <= tol).all()), (step, nm, gap.max().item(), tol.min().item())
+            # (the 30-token cam / gaze targets select 6-10 rows per step: one near-tie row is already 10 %)
+            assert am > (0.99 if peaked else 0.9) or int(mism.sum()) <= 1, (step, nm, am)
         # the sampler (temperature 0.01 -> nearly greedy on the CFG-mixed logits) agrees with the reference's draws
         mine = info["samples"][0].cpu().numpy()
         agree_total += (mine == g[f"s{step}.samples"][0]).sum()
@@ -127,8 +139,8 @@ def test_roar_cfg_generation_matches_reference(fixture):
     # random-init weights give nearly flat logits: bf16 noise flips near-ties there (the gap bound above is the real bar);
     # with the peaked head the sampled tokens themselves agree
     assert agree_total / n_total > (0.99 if peaked else 0.7), agree_total / n_total
-    assert np.array_equal(md["tok_depth"]["tensor"].cpu().numpy().astype(np.int32), g["final_tokens"])   # teacher-forced state
-    assert (~md["tok_depth"]["input_mask"]).all() and md["tok_depth"]["target_mask"].all()
+    assert np.array_equal(md[target]["tensor"].cpu().numpy().astype(np.int32), g["final_tokens"])   # teacher-forced state
+    assert (~md[target]["input_mask"]).all() and md[target]["target_mask"].all()
 
 
 def test_generate_end_to_end_runs():
@@ -174,23 +186,28 @@ def test_hipgraph_replay_is_bitwise_identical():
     assert torch.equal(a, b)
 
 
-def test_whole_schedule_graph_matches_eager_generation():
-    """BASELINE config 4 "hipGraph-captured decode": the 6 encoder-decoder passes, 3 sampler launches and the token
+@pytest.mark.parametrize("cfg_name,cond,target,n_target,steps", [
+    ("ego_gen_384_2e_2d", "tok_rgb", "tok_depth", 5120, 3),          # eval_model_rgb2depth.py
+    ("ego_b_2e_2d", "tok_rgb", "tok_gaze", 30, 5),                   # eval_model_rgb2gaze.py (sequence target, four modalities)
+    ("ego_b_2e_2d", "tok_depth", "tok_rgb", 5120, 6),                # eval_model_depth2rgb.py
+])
+def test_whole_schedule_graph_matches_eager_generation(cfg_name, cond, target, n_target, steps):
+    """BASELINE config 4 "hipGraph-captured decode": the 2 x steps encoder-decoder passes, the sampler launches and the token
     scatters of a schedule replayed from ONE captured graph produce the tokens of the eager path, bit for bit, also
-    when the graph is replayed on new clips and seeds."""
-    cfg = MODEL_CFGS["ego_gen_384_2e_2d"]
+    when the graph is replayed on new clips and seeds - for the schedules of the reference's generation scripts."""
+    cfg = MODEL_CFGS[cfg_name]
     eng = Engine(cfg, "cuda:0", max_batch=2, n_enc=64, n_dec=64)
     eng.init_random(6)
-    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+    sch = build_chained_generation_schedules([cond], [target], [n_target], ["roar"], [steps], ["linear"], [0.01], ["constant"],
                                              [2.0], ["constant"], cfg_grow_conditioning=True)
     eager, graphed = GenerationSampler(eng, use_graphs=False), GenerationSampler(eng)
     for trial in range(3):
-        sample = {"tok_rgb": {"tensor": synth.randint(f"ws{trial}.rgb", (2, 5, 32, 32), 64000, seed=trial).to(DEV)}}
-        sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", 2, 5120, DEV)
-        sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+        sample = {cond: {"tensor": synth.randint(f"ws{trial}.{cond}", (2, 5, 32, 32), 64000, seed=trial).to(DEV)}}
+        sample = init_empty_target_modality(sample, MODALITY_INFO, target, 2, n_target, DEV)
+        sample = init_full_input_modality(sample, MODALITY_INFO, cond, DEV)
         a = eager.generate(sample, sch, top_p=0.8, seed=10 + trial)
         b = graphed.generate_graphed(sample, sch, top_p=0.8, seed=10 + trial)
-        assert torch.equal(a["tok_depth"]["tensor"], b["tok_depth"]["tensor"]), trial
-        assert torch.equal(a["tok_depth"]["input_mask"], b["tok_depth"]["input_mask"])
-        assert b["tok_depth"]["target_mask"].all() and sample["tok_depth"]["input_mask"].all()
+        assert torch.equal(a[target]["tensor"], b[target]["tensor"]), trial
+        assert torch.equal(a[target]["input_mask"], b[target]["input_mask"])
+        assert b[target]["target_mask"].all() and sample[target]["input_mask"].all()
     assert sum(1 for k in eng._graphs if k[0] == "generate") == 1          # one graph served all three clips
