@@ -69,6 +69,8 @@ def get_args(argv=None):
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--print_freq", default=10, type=int)
     p.add_argument("--max_steps", default=-1, type=int)
+    p.add_argument("--resume", default="", help="checkpoint written by this script (model + optimiser state + epoch)")
+    p.add_argument("--auto_resume", action="store_true", help="resume from the newest checkpoint-N.pth in --output_dir, if any")
     known, rest = cfg_parser.parse_known_args(argv)
     if known.config:
         with open(known.config) as f:
@@ -176,8 +178,24 @@ def main(args):
     if rank == 0:
         print(f"model {args.model}: {model.module.engine.num_params() / 1e6:.1f} M params; world {world}; global batch {global_batch}; "
               f"lr {args.lr:.3e}; {total_steps} optimiser steps", flush=True)
-    start = 0
-    for epoch in range(epochs):
+    start, first_epoch = 0, 0
+    # resume (the reference's auto_load_model, egom2p/utils/checkpoint.py:123-157: explicit --resume, else the newest
+    # checkpoint-N.pth of the output directory); only this script's own files, read with weights_only=True
+    if not args.resume and args.auto_resume and args.output_dir and os.path.isdir(args.output_dir):
+        have = [int(f[len("checkpoint-"):-4]) for f in os.listdir(args.output_dir)
+                if f.startswith("checkpoint-") and f.endswith(".pth") and f[len("checkpoint-"):-4].isdigit()]
+        if have:
+            args.resume = os.path.join(args.output_dir, f"checkpoint-{max(have)}.pth")
+    if args.resume:
+        ck = torch.load(args.resume, map_location="cpu", weights_only=True)
+        model.module.load_state_dict(ck["model"])
+        if "optimizer" in ck:
+            optimizer.load_state_dict(ck["optimizer"])
+        first_epoch = int(ck.get("epoch", -1)) + 1
+        start = first_epoch * (steps_per_epoch // args.accum_iter)
+        if rank == 0:
+            print(f"resumed {args.resume}: continuing at epoch {first_epoch}, optimiser step {start}", flush=True)
+    for epoch in range(first_epoch, epochs):
         loader = SyntheticClips(mcfg, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps_per_epoch,
                                 seed=seed * 1000 + epoch)
         stats = train_one_epoch(model, loader, optimizer, scaler, args, epoch, start, lr_values, device)
@@ -187,7 +205,8 @@ def main(args):
             if args.output_dir:
                 os.makedirs(args.output_dir, exist_ok=True)
                 torch.save({"model": model.module.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch,
-                            "args": vars(args)}, os.path.join(args.output_dir, f"checkpoint-{epoch}.pth"))
+                            "args": {k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, type(None)))}},
+                           os.path.join(args.output_dir, f"checkpoint-{epoch}.pth"))
         if args.max_steps > 0:
             break
 

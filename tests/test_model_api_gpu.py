@@ -192,3 +192,48 @@ def test_frozen_encoder_steps_match_torch_adamw_on_the_unfrozen_subset():
         for n in frozen:
             assert torch.equal(named[n].detach(), frozen0[n]), n
         assert float(model.engine.G.abs().max().item()) == 0.0    # frozen ranges are cleared too
+
+
+def test_training_script_resumes_where_it_stopped(tmp_path):
+    """run_training_egom2p.py --auto_resume (the reference's auto_load_model, utils/checkpoint.py:123-157): a run that is
+    interrupted after its first epoch and restarted ends with the parameters and AdamW state of the uninterrupted run
+    (same clips, same cosine schedule position).  Float atomics in the embedding / LayerNorm-weight gradients make two runs
+    equal to fp32 round-off, not bit for bit."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_training_egom2p_amd", os.path.join(root, "run_training_egom2p.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    common = ["--model", "egom2p_tiny_6e_6d_swiglu_nobias", "--in_domains", "tok_cam-tok_gaze", "--out_domains", "tok_cam-tok_gaze",
+              "--num_input_tokens", "32", "--num_target_tokens", "32", "--batch_size", "4", "--epochs", "2", "--epoch_size", "8",
+              "--clip_grad", "1.0", "--blr", "1e-3", "--print_freq", "100", "--seed", "3"]
+    env_keys = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        a_dir, b_dir = str(tmp_path / "a"), str(tmp_path / "b")
+        R.main(R.get_args(common + ["--output_dir", a_dir]))
+        # interrupted run: the second epoch never starts
+        real = R.train_one_epoch
+
+        def one_epoch_then_die(model, loader, optimizer, scaler, args, epoch, *rest):
+            if epoch >= 1:
+                raise KeyboardInterrupt
+            return real(model, loader, optimizer, scaler, args, epoch, *rest)
+
+        R.train_one_epoch = one_epoch_then_die
+        with pytest.raises(KeyboardInterrupt):
+            R.main(R.get_args(common + ["--output_dir", b_dir]))
+        R.train_one_epoch = real
+        assert os.path.exists(os.path.join(b_dir, "checkpoint-0.pth")) and not os.path.exists(os.path.join(b_dir, "checkpoint-1.pth"))
+        R.main(R.get_args(common + ["--output_dir", b_dir, "--auto_resume"]))
+    finally:
+        os.environ.update(env_keys)
+    ca = torch.load(os.path.join(a_dir, "checkpoint-1.pth"), map_location="cpu", weights_only=True)
+    cb = torch.load(os.path.join(b_dir, "checkpoint-1.pth"), map_location="cpu", weights_only=True)
+    assert ca["optimizer"]["t"] == cb["optimizer"]["t"] == 4
+    for k, v in ca["model"].items():
+        d = (v.float() - cb["model"][k].float()).norm().item()
+        assert d <= 1e-5 * max(v.float().norm().item(), 1e-6), (k, d)
+    for k in ("m", "v"):
+        d = (ca["optimizer"][k] - cb["optimizer"][k]).norm().item()
+        assert d <= 1e-4 * ca["optimizer"][k].norm().item(), (k, d)
