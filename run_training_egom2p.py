@@ -64,6 +64,8 @@ def get_args(argv=None):
     p.add_argument("--warmup_tokens", default=-1, type=float)
     p.add_argument("--epoch_size", default=1000, type=int, help="samples per 'epoch'")
     p.add_argument("--data", default="synthetic")
+    p.add_argument("--mask", default="device", choices=["device", "host"],
+                   help="where the synthetic clips' token budgets / masks are drawn (device: ego_budget_dirichlet + ego_clip_synth)")
     p.add_argument("--data_config", default="")
     p.add_argument("--output_dir", default="")
     p.add_argument("--seed", default=0, type=int)
@@ -100,18 +102,29 @@ def cosine_scheduler(base, final, total_steps, warmup_steps):
 
 
 class SyntheticClips:
-    """Iterable of batched `mod_dict`s with ragged (Dirichlet) or canonical budgets."""
+    """Iterable of batched `mod_dict`s: ragged budgets from the reference's Dirichlet mixture (UnifiedMasking,
+    egom2p/data/masking.py:181-266) or the canonical split.  mask="device" (default): budgets, permutations, masks and ids are
+    made by the HIP kernels (ego_budget_dirichlet + ego_clip_synth) - no host tensors, no H2D copy; mask="host": the host
+    generator the parity fixtures were made with."""
 
-    def __init__(self, model_cfg: ModelCfg, batch, n_in, n_tgt, steps, seed, ragged=True):
+    def __init__(self, model_cfg: ModelCfg, batch, n_in, n_tgt, steps, seed, ragged=True, mask="device", device="cuda"):
         self.cfg, self.batch, self.n_in, self.n_tgt, self.steps, self.seed, self.ragged = model_cfg, batch, n_in, n_tgt, steps, seed, ragged
+        self.mask, self.device = mask, device
 
     def __len__(self):
         return self.steps
 
     def __iter__(self):
         for i in range(self.steps):
-            b = synth.dirichlet_budgets(self.cfg, self.batch, self.n_in, self.n_tgt, seed=self.seed * 7919 + i) if self.ragged else None
-            yield synth.make_clip_batch(self.cfg, self.batch, b, seed=self.seed, sample_offset=i * self.batch)
+            if self.mask == "device":
+                if self.ragged:
+                    yield synth.make_clip_batch_device_masked(self.cfg, self.batch, self.n_in, self.n_tgt, seed=self.seed,
+                                                              sample_offset=i * self.batch, device=self.device)
+                else:
+                    yield synth.make_clip_batch_device(self.cfg, self.batch, None, seed=self.seed, sample_offset=i * self.batch, device=self.device)
+            else:
+                b = synth.dirichlet_budgets(self.cfg, self.batch, self.n_in, self.n_tgt, seed=self.seed * 7919 + i) if self.ragged else None
+                yield synth.make_clip_batch(self.cfg, self.batch, b, seed=self.seed, sample_offset=i * self.batch)
 
 
 def train_one_epoch(model, loader, optimizer, scaler, args, epoch, start_steps, lr_values, device):
@@ -197,7 +210,7 @@ def main(args):
             print(f"resumed {args.resume}: continuing at epoch {first_epoch}, optimiser step {start}", flush=True)
     for epoch in range(first_epoch, epochs):
         loader = SyntheticClips(mcfg, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps_per_epoch,
-                                seed=seed * 1000 + epoch)
+                                seed=seed * 1000 + epoch, mask=args.mask, device=device)
         stats = train_one_epoch(model, loader, optimizer, scaler, args, epoch, start, lr_values, device)
         start += steps_per_epoch // args.accum_iter
         if rank == 0:
