@@ -181,6 +181,7 @@ def init_distributed_mode(args=None, backend: Optional[str] = None):
     """Env-var rank discovery + init_process_group (egom2p/utils/dist.py:78-100); "nccl" is RCCL on ROCm."""
     import datetime
     import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this pool (no effect once HIP is up)
     if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
         if args is not None:
             args.distributed = False
