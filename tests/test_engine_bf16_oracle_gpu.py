@@ -30,7 +30,7 @@ SENS_FACTOR = 2.5       # a gradient may differ from the bf16 oracle by 2.5 x th
 LOSS_TOL = 3e-4
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged"])
 def test_engine_matches_bf16_mode_oracle(case):
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]
