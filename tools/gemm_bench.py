@@ -36,6 +36,19 @@ def main():
         t = timeit(lambda: ops.gemm_nt(A, B, C, M, N, K, L.EPI_RESID, R=R))
         res[f"nt_resid {M}x{N}x{K}"] = round(2.0 * M * N * K / t / 1e12, 1)
         del A, B, C, R
+    # the two fused SwiGLU launches (fc1||fc3 + gate; fc2 dgrad + gate backward)
+    for M, F, K in ([] if os.environ.get('SKIP_NT') == '1' else [(65536, 2048, 768), (131072, 2048, 768)]):
+        X = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+        W13 = ((torch.rand(2 * F, K, device=dev) * 2 - 1) * 0.05).bfloat16()
+        ab = torch.empty(M, 2 * F, device=dev, dtype=torch.bfloat16)
+        h = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm_nt_swiglu_fwd(X, W13, ab, h, M, F, K))
+        res[f"swiglu_fwd {M}x{F}x{K}"] = round(2.0 * M * 2 * F * K / t / 1e12, 1)
+        W2t = ((torch.rand(F, K, device=dev) * 2 - 1) * 0.05).bfloat16()
+        dab = torch.empty(M, 2 * F, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm_nt_swiglu_bwd(X, W2t, ab, dab, M, F, K))
+        res[f"swiglu_bwd {M}x{F}x{K}"] = round(2.0 * M * F * K / t / 1e12, 1)
+        del X, W13, ab, h, W2t, dab
     if os.environ.get("SKIP_TN") != "1":
         slab = torch.empty(64 * 1024 * 1024 // 4, device=dev)
         for M, Ni, Nj in [(65536, 768, 768), (32768, 2304, 768), (32768, 768, 768), (32768, 4096, 768), (32768, 768, 2048), (65536, 2304, 768), (65536, 4096, 768), (65536, 768, 2048), (65536, 1536, 768), (16144, 64000, 768)]:
