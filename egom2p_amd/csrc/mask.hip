@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1024) void clip_synth_kernel(const uint64_t* __rest
         }
         const bool is_in = rank < kin, is_tg = rank >= kin && rank < kin + ktg;
         const long o = (long)b * n + i;
-        ids[o] = (long)((splitmix(ki, (uint64_t)i) >> 11) % (uint64_t)vocab);
+        if (ids) ids[o] = (long)((splitmix(ki, (uint64_t)i) >> 11) % (uint64_t)vocab);
         in_mask[o] = is_in ? 0 : 1;
         tg_mask[o] = is_tg ? 0 : 1;
         dam[o] = 0;
@@ -164,7 +164,7 @@ extern "C" int ego_budget_dirichlet(const ego_budget_desc* d, const void* clip_k
 extern "C" int ego_clip_synth(const void* key_ids, const void* key_perm, const int* k_in, const int* k_tgt, int B, int n, int vocab,
                               long* ids, void* input_mask, void* target_mask, int* dam, hipStream_t stream) {
     if (B <= 0) return EGO_OK;
-    if (n <= 0 || n > SYN_MAX_N || vocab <= 0) return EGO_ERR_ARG;
+    if (n <= 0 || n > SYN_MAX_N || (ids && vocab <= 0)) return EGO_ERR_ARG;
     EGO_LAUNCH(clip_synth_kernel, dim3(B), dim3(1024), 0, stream, (const uint64_t*)key_ids, (const uint64_t*)key_perm, k_in, k_tgt, n,
                vocab, ids, (unsigned char*)input_mask, (unsigned char*)target_mask, dam);
     LAUNCH_CHECK();

@@ -89,8 +89,9 @@ def gemm_tn(P, Q, C0, Ni, Nj, M, C1=None, split_row=0, rows0=None, rows1=0, m_ra
 
 
 def clip_synth(key_ids, key_perm, k_in, k_tgt, n, vocab, ids, input_mask, target_mask, dam):
-    """one modality of the synthetic input contract for B = len(key_ids) clips, generated on the device"""
-    _need_cuda(ids)
+    """one modality of the synthetic input contract for B = len(key_ids) clips, generated on the device (ids=None: masks and
+    decoder-attention marker only)"""
+    _need_cuda(input_mask)
     check(L.load().ego_clip_synth(_p(key_ids), _p(key_perm), _p(k_in), _p(k_tgt), key_ids.numel(), n, vocab, _p(ids),
                                   _p(input_mask), _p(target_mask), _p(dam), _stream()), "ego_clip_synth")
 

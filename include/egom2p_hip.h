@@ -186,7 +186,8 @@ int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t, long ldw, 
  * random permutation of the positions, first k_in inputs, next k_tgt targets, decoder_attention_mask = k_tgt at the
  * first target).  ids[B,n] int64 in [0,vocab), masks[B,n] uint8 (1 = ignore), dam[B,n] int32.  key_ids / key_perm:
  * one 64-bit stream key per clip (host: sha256 of "<seed>:clip<s>.<mod>.ids|perm"); bit-identical to
- * egom2p_amd/synth.py:make_clip_batch.  n <= 8192. */
+ * egom2p_amd/synth.py:make_clip_batch.  n <= 8192.  ids may be NULL: masks and marker only, for clips whose tokens already
+ * exist (egom2p_amd/masking.py: UnifiedMasking on real token tensors). */
 int ego_clip_synth(const void* key_ids, const void* key_perm, const int* k_in, const int* k_tgt, int B, int n, int vocab,
                    long* ids, void* input_mask, void* target_mask, int* dam, hipStream_t stream);
 

@@ -236,3 +236,48 @@ def test_row_list_kernels_and_sparse_exchange_single_rank():
         assert torch.equal(fl.bool() | ~nz, torch.ones_like(nz))              # every row with a gradient is flagged
         slot_rows = eng.ce["tok"][:2][eng.ce["slot"][:2] == cfg.mods.index(m)].long().unique()
         assert torch.equal(torch.nonzero(fl).flatten(), slot_rows)            # and exactly the kept token ids are
+
+
+def test_unified_masking_on_real_token_tensors():
+    """egom2p_amd.masking.UnifiedMasking: the reference's `UnifiedMasking.__call__` (data/masking.py:519-560, image_mask
+    :236-266) for a batch of EXISTING token tensors on the device - the contract of every returned entry, per clip and
+    modality, and that the engine trains on it."""
+    from egom2p_amd.engine import Engine
+    from egom2p_amd.masking import UnifiedMasking
+    from egom2p_amd.model import MODALITY_INFO
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    B = 12
+    info = {m.name: MODALITY_INFO[m.name] for m in cfg.mods}
+    toks = {m.name: synth.randint(f"um.{m.name}", (B,) + (m.grid if m.kind == "video" else (m.max_tokens,)), m.vocab_size, seed=5).cuda()
+            for m in cfg.mods}
+    masker = UnifiedMasking(info, None, input_tokens_range=(1024, 2048), target_tokens_range=2048, seed=7)
+    md = masker(toks)
+    n_in_tot, n_tg_tot = np.zeros(B, np.int64), np.zeros(B, np.int64)
+    for m in cfg.mods:
+        e = md[m.name]
+        assert e["tensor"] is toks[m.name]                                    # tokens pass through untouched
+        im, tm, dam = e["input_mask"].cpu().numpy(), e["target_mask"].cpu().numpy(), e["decoder_attention_mask"].cpu().numpy()
+        assert im.shape == tm.shape == dam.shape == (B, m.max_tokens) and im.dtype == bool
+        assert not ((~im) & (~tm)).any()                                      # inputs and targets are disjoint
+        for b in range(B):
+            k_tg = int((~tm[b]).sum())
+            n_in_tot[b] += int((~im[b]).sum()); n_tg_tot[b] += k_tg
+            nz = np.nonzero(dam[b])[0]
+            if k_tg == 0:
+                assert nz.size == 0
+            else:                                                             # target count at the first target position (:262-264)
+                assert nz.tolist() == [int(np.argmax(~tm[b]))] and dam[b, nz[0]] == k_tg
+    assert (n_in_tot >= 1) .all() and (n_in_tot <= 2048).all() and (n_tg_tot <= 2048).all()
+    assert n_in_tot.min() < n_in_tot.max()                                    # the token count itself is drawn from the range
+    # a second call masks differently, a second instance with the same seed reproduces the first call
+    md2 = masker(toks)
+    assert not torch.equal(md2["tok_rgb"]["input_mask"], md["tok_rgb"]["input_mask"])
+    again = UnifiedMasking(info, None, input_tokens_range=(1024, 2048), target_tokens_range=2048, seed=7)(toks)
+    assert all(torch.equal(again[k]["input_mask"], md[k]["input_mask"]) and torch.equal(again[k]["target_mask"], md[k]["target_mask"]) for k in md)
+    eng = Engine(cfg, "cuda:0", max_batch=B, n_enc=2048, n_dec=2048)
+    eng.init_random(3)
+    loss, mod_loss = eng.forward(md, dec_order=[m.name for m in cfg.mods])
+    eng.backward(1.0)
+    assert np.isfinite(float(loss)) and 5.0 < float(loss) < 12.0 and torch.isfinite(eng.G).all()
+    with pytest.raises(NotImplementedError):
+        UnifiedMasking({"caption": {"type": "seq", "max_tokens": 256}}, None, 128, 128)
