@@ -535,7 +535,11 @@ class Engine:
         y0 = self.dec[0]["x"] if cfg.decoder_depth else self.y_out
         ops.embed_fwd(None, [self.pos[m.name] for m in dmods], [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods],
                       self.p["mask_token"], cd["slot"], cd["local"], cd["tok"], y0, None, RM, D)
-        self.canon.copy_(torch.tensor([mods.index(m) for m in dmods], dtype=I32), non_blocking=True)
+        ckey = tuple(m.name for m in dmods)
+        cache = self.__dict__.setdefault("_canon_dev", {})
+        if ckey not in cache:                        # one small H2D copy per decoder order, ever (never inside a graph capture)
+            cache[ckey] = torch.tensor([mods.index(m) for m in dmods], dtype=I32).to(self.dev)
+        self.canon.copy_(cache[ckey])
         ops.loss_perm(cd["seg"], self.canon, cd["slot"], cd["tok"], B, M, self.n_mods, self.perm, self.tgt_perm,
                       self.ranges, self.perm_base)
 
