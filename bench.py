@@ -116,11 +116,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a one-GPU box: EGOM2P_DIST_BACKEND=gloo EGOM2P_ONE_DEVICE=1 puts every rank on
+    # device 0 and exchanges over gloo (RCCL refuses two ranks on one device); never set by the driver
+    if os.environ.get("EGOM2P_ONE_DEVICE") == "1":
+        local = 0
     if world > 1 or os.environ.get("EGOM2P_FORCE_REDUCER") == "1":
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("EGOM2P_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dev = f"cuda:{local}"
