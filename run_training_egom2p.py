@@ -64,6 +64,8 @@ def get_args(argv=None):
     p.add_argument("--warmup_tokens", default=-1, type=float)
     p.add_argument("--epoch_size", default=1000, type=int, help="samples per 'epoch'")
     p.add_argument("--data", default="synthetic")
+    p.add_argument("--data_path", default="", help="token shards in the reference's layout, e.g. "
+                   "'root/[rgb,depth,cam,gaze]/holoassist/token/shard-{000000..000195}.tar' (README_DATA.md); masked on the device")
     p.add_argument("--mask", default="device", choices=["device", "host"],
                    help="where the synthetic clips' token budgets / masks are drawn (device: ego_budget_dirichlet + ego_clip_synth)")
     p.add_argument("--data_config", default="")
@@ -125,6 +127,32 @@ class SyntheticClips:
             else:
                 b = synth.dirichlet_budgets(self.cfg, self.batch, self.n_in, self.n_tgt, seed=self.seed * 7919 + i) if self.ragged else None
                 yield synth.make_clip_batch(self.cfg, self.batch, b, seed=self.seed, sample_offset=i * self.batch)
+
+
+class ShardClips:
+    """Real token shards (egom2p_amd/data.py: the reference's modified-WebDataset layout) -> GPU -> `UnifiedMasking` on the
+    device: what the reference does with webdataset + CPU workers (`build_wds_fm_pretraining_dataloader`)."""
+
+    def __init__(self, args, model, epoch, rank, world, steps, seed, device):
+        from egom2p_amd.data import TokenShards
+        from egom2p_amd.masking import UnifiedMasking
+        self.ds = TokenShards(args.data_path, args.batch_size, rank=rank, world=world, shuffle_seed=seed)
+        self.ds.set_epoch(epoch)
+        info = {m: MODALITY_INFO[m] for m in args.in_domains}
+        missing = set(info) - set(self.ds.names.values())
+        if missing:
+            raise ValueError(f"--data_path has no folder for {sorted(missing)} (folders: {self.ds.folders})")
+        self.mask = UnifiedMasking(info, None, args.num_input_tokens, args.num_target_tokens, seed=seed * 1000 + epoch, device=device)
+        self.steps, self.device = steps, device
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i, batch in enumerate(self.ds):
+            if i >= self.steps:
+                break
+            yield self.mask({k: v.to(self.device, non_blocking=True) for k, v in batch.items() if k in self.mask.names})
 
 
 def train_one_epoch(model, loader, optimizer, scaler, args, epoch, start_steps, lr_values, device):
@@ -209,8 +237,11 @@ def main(args):
         if rank == 0:
             print(f"resumed {args.resume}: continuing at epoch {first_epoch}, optimiser step {start}", flush=True)
     for epoch in range(first_epoch, epochs):
-        loader = SyntheticClips(mcfg, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps_per_epoch,
-                                seed=seed * 1000 + epoch, mask=args.mask, device=device)
+        if args.data_path:
+            loader = ShardClips(args, model.module, epoch, rank, world, steps_per_epoch, seed, device)
+        else:
+            loader = SyntheticClips(mcfg, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps_per_epoch,
+                                    seed=seed * 1000 + epoch, mask=args.mask, device=device)
         stats = train_one_epoch(model, loader, optimizer, scaler, args, epoch, start, lr_values, device)
         start += steps_per_epoch // args.accum_iter
         if rank == 0:

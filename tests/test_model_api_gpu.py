@@ -237,3 +237,44 @@ def test_training_script_resumes_where_it_stopped(tmp_path):
     for k in ("m", "v"):
         d = (ca["optimizer"][k] - cb["optimizer"][k]).norm().item()
         assert d <= 1e-4 * ca["optimizer"][k].norm().item(), (k, d)
+
+
+def test_training_script_reads_reference_token_shards(tmp_path):
+    """`run_training_egom2p.py --data_path`: token shards in the reference's on-disk layout (README_DATA.md: one tar per
+    modality and shard, '<key>.npz' members) are read by egom2p_amd.data.TokenShards, masked on the device by
+    egom2p_amd.masking.UnifiedMasking and trained on."""
+    import importlib.util
+    import io
+    import json
+    import os
+    import tarfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_training_egom2p_amd2", os.path.join(root, "run_training_egom2p.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    rng = np.random.default_rng(1)
+    for f in ("cam", "gaze"):
+        d = tmp_path / f / "toy" / "token"
+        os.makedirs(d)
+        for s in range(2):
+            with tarfile.open(d / f"shard-{s:06d}.tar", "w") as tar:
+                for i in range(8):
+                    b = io.BytesIO()
+                    np.savez(b, rng.integers(0, 256, size=30).astype(np.int32))
+                    info = tarfile.TarInfo(f"clip{s}_{i:02d}.npz")
+                    info.size = b.getbuffer().nbytes
+                    b.seek(0)
+                    tar.addfile(info, b)
+    out_dir = str(tmp_path / "out")
+    argv = ["--model", "egom2p_tiny_6e_6d_swiglu_nobias", "--in_domains", "tok_cam-tok_gaze", "--out_domains", "tok_cam-tok_gaze",
+            "--num_input_tokens", "32", "--num_target_tokens", "32", "--batch_size", "4", "--epochs", "1", "--epoch_size", "16",
+            "--clip_grad", "1.0", "--blr", "1e-3", "--print_freq", "100", "--output_dir", out_dir,
+            "--data_path", f"{tmp_path}/[cam,gaze]/toy/token/shard-{{000000..000001}}.tar"]
+    env_keys = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        R.main(R.get_args(argv))
+    finally:
+        os.environ.update(env_keys)
+    ck = torch.load(os.path.join(out_dir, "checkpoint-0.pth"), map_location="cpu", weights_only=True)
+    assert ck["optimizer"]["t"] == 4                                          # 16 clips / batch 4
+    assert all(torch.isfinite(v.float()).all() for v in ck["model"].values())
