@@ -64,3 +64,20 @@ def test_profiler_cost_functions_accept_the_ops_signatures():
         for n, p in op.parameters.items():                   # parameters with defaults are the ones callers pass by keyword
             if p.default is not p.empty:
                 assert n in cs.parameters or var_kw, f"profiler cost function of ops.{name} does not accept keyword '{n}'"
+
+
+def test_bench_counts_the_flops_the_survey_states():
+    """bench.py's `algorithmic_tflops_per_gpu` / `mfma_frac_end_to_end` come from `flops_per_clip`: for the canonical ego-b
+    split it must be SURVEY.md section 8(d)'s block-sparse count (1.397 TF forward, 4.19 TF forward + backward per clip =
+    406.9 MFLOP per clip position) - a reporting bug here would move every efficiency figure."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from egom2p_amd import synth
+    from egom2p_amd.config import MODEL_CFGS
+    f = bench.flops_per_clip(MODEL_CFGS["egom2p_base_12e_12d_swiglu_nobias"], synth.CANONICAL_BUDGETS, 2048, 2048)
+    assert abs(f / 1.397e12 - 1.0) < 1e-3
+    assert abs(3.0 * f / 10300 / 406.9e6 - 1.0) < 1e-3
