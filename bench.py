@@ -84,6 +84,47 @@ def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
             "loss": head["loss"], "runs": runs}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which has not touched the
+    GPU and never will) starts the N ranks as ONE child `python -m torch.distributed.run` (one rank per GPU, RCCL), lets
+    the child's stderr through, relays rank 0's single JSON line and exits with the child's code.  No exec: a process
+    that has initialised the GPU must never be replaced, and the parent stays GPU-free so that it could be.
+    Reference launch: torchrun (README_TRAINING.md:40-43), egom2p/utils/dist.py:78-100, DDP at run_training_egom2p.py:514."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise HIP on this image
+    one_dev = os.environ.get("EGOM2P_ONE_DEVICE") == "1"
+    if n_dev < args.gpus and not one_dev:
+        print(f"[bench] --gpus {args.gpus} but only {n_dev} GPU(s) visible; refusing to time fewer ranks than asked "
+              f"(rehearsal on one device: EGOM2P_DIST_BACKEND=gloo EGOM2P_ONE_DEVICE=1)", file=sys.stderr)
+        sys.exit(2)
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = p.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.lstrip().startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(out.decode(errors="replace"))
+        print(f"[bench] self-launch failed: rc {p.returncode}, {len(lines)} JSON line(s)", file=sys.stderr)
+        sys.exit(p.returncode or 1)
+    rec = json.loads(lines[0])
+    if rec.get("ranks_seen") != args.gpus:
+        print(f"[bench] ranks_seen {rec.get('ranks_seen')} != --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(1)
+    rec["launcher"] = "self (bench.py started torch.distributed.run)"
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +141,11 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
     args = ap.parse_args()
+    under_launcher = "WORLD_SIZE" in os.environ and ("TORCHELASTIC_RUN_ID" in os.environ or int(os.environ["WORLD_SIZE"]) > 1)
+    if args.gpus > 1 and not under_launcher:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):     # a stray WORLD_SIZE=1 from a wrapper shell is not a launcher
+            os.environ.pop(k, None)
+        self_launch(args, sys.argv[1:])
 
     # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are sent to stderr for the duration of the run
@@ -125,10 +171,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(os.environ.get("EGOM2P_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        # a line labelled --gpus N must come from N ranks: never time fewer (or more) ranks than asked
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
+        sys.exit(2)
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
+    ranks_seen, rank_devices = 1, [f"{dev} ({torch.cuda.get_device_name(local)})"]
+    if dist.is_initialized():
+        ranks_seen = dist.get_world_size()
+        gathered = [None] * ranks_seen
+        prop = torch.cuda.get_device_properties(local)
+        dist.all_gather_object(gathered, f"rank{rank}:cuda:{local}:{prop.name}:{getattr(prop, 'uuid', '')}")
+        rank_devices = gathered
 
     cfg = MODEL_CFGS[args.model]
     n_enc = n_dec = 2048
@@ -184,6 +240,7 @@ def main():
         "config": {"workload": f"{args.model} mod4, synthetic 10300-position clips (1009+1009 rgb, 1009+1009 depth, 15+15 cam, "
                                f"15+15 gaze kept -> N=M=2048), bf16 MFMA GEMM/attention, fp32 residual/LN/CE/AdamW",
                    "clips_per_gpu_per_step": clips, "micro_batch": mb, "global_batch": clips * world, "parallelism": f"dp{world}"},
+        "ranks_seen": ranks_seen, "rank_devices": rank_devices,
         "clips_per_s": value / 10300.0, "final_loss": final_loss,
         "algorithmic_tflops_per_gpu": e2e_tflops, "mfma_frac_end_to_end": e2e_tflops / PEAK_BF16_TFLOPS,
     }

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOM2P_HIP_LIB", os.path.join(_HERE, "libegom2p_hip.so"))   # override: kernel experiments
 MAX_MODS = 8
 
+ABI_VERSION = 2          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
 EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -118,8 +119,8 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = i32
-        if lib.ego_abi_version() != 1:
-            raise EgoHipError("libegom2p_hip.so ABI version mismatch")
+        if lib.ego_abi_version() != ABI_VERSION:
+            raise EgoHipError(f"libegom2p_hip.so ABI version {lib.ego_abi_version()} != binding {ABI_VERSION}: rebuild (make -C egom2p_amd/csrc)")
         # kernel experiments: EGO_GEMM_NT256 / EGO_GEMM_TN256 = 0 | 1 | 2 pick the GEMM tile family (the library itself
         # reads no environment; this is the same call tests make through ops.gemm_kernel_mode)
         if "EGO_GEMM_NT256" in os.environ or "EGO_GEMM_TN256" in os.environ:

@@ -102,7 +102,9 @@ struct Rng {
         float lg[EGO_MAX_MODS], mx = -3.0e38f, sum = 0.f;
         for (int i = 0; i < n; ++i) { lg[i] = log_gamma(alpha[i]); mx = fmaxf(mx, lg[i]); }
         for (int i = 0; i < n; ++i) { p[i] = expf(lg[i] - mx); sum += p[i]; }
-        for (int i = 0; i < n; ++i) p[i] /= sum;
+        // torch's Dirichlet.sample() (masking.py:192) clamps every float32 component to [FLT_MIN, 1 - 2^-24] (ATen
+        // _s_dirichlet): a one-hot draw is never exactly 1, floor(p * N) then leaves a token over - part of the reference's law
+        for (int i = 0; i < n; ++i) p[i] = fminf(fmaxf(p[i] / sum, 1.17549435e-38f), 0.99999994f);
     }
 };
 

@@ -66,8 +66,12 @@ class TokenShards:
 
     def __init__(self, data_path: str, batch_size: int, rename: Optional[Dict[str, str]] = None, rank: int = 0, world: int = 1,
                  shuffle_seed: Optional[int] = None, drop_last: bool = True, modalities: Optional[Sequence[str]] = None,
-                 pin_memory: bool = True):
+                 pin_memory: bool = True, vocab: Optional[Dict[str, int]] = None):
+        """shuffle_seed must be the SAME on every rank: the shard list is shuffled with (seed, epoch) and then dealt
+        `order[rank::world]`, which is a partition only if every rank shuffles alike.  vocab: model modality name -> vocabulary
+        size; every batch is range-checked against it on the host (ids index embedding tables on the device)."""
         self.batch, self.rank, self.world, self.seed, self.drop_last = int(batch_size), rank, world, shuffle_seed, drop_last
+        self.vocab = dict(vocab or {})
         self.pin = pin_memory and torch.cuda.is_available()
         self.epoch = 0
         if os.path.isdir(data_path):
@@ -128,9 +132,40 @@ class TokenShards:
         if buf and not self.drop_last:
             yield self._collate(buf)
 
+    def batches(self, steps: int) -> Iterator[Dict[str, torch.Tensor]]:
+        """Exactly `steps` batches on EVERY rank, whatever its share of the shards holds: when the rank's shards are
+        exhausted the pass restarts on the next epoch's shuffle (the reference's `wds.ResampledShards(...).with_epoch(n)`
+        is likewise an endless stream cut to a fixed step count, unified_datasets.py:430-470).  Ranks that issue different
+        numbers of steps would issue different numbers of gradient all-reduces and hang."""
+        done, epoch0 = 0, self.epoch
+        while done < steps:
+            got = 0
+            for b in self:
+                yield b
+                got += 1
+                done += 1
+                if done == steps:
+                    break
+            if got == 0:
+                self.epoch = epoch0
+                raise RuntimeError(f"TokenShards: rank {self.rank} of {self.world} cannot form one batch of {self.batch} samples "
+                                   f"from its share of the shards")
+            self.epoch += 1
+        self.epoch = epoch0
+
     def _collate(self, buf) -> Dict[str, torch.Tensor]:
         out = {}
         for f in self.folders:
-            t = torch.from_numpy(np.stack([b[f] for b in buf]).astype(np.int64))     # `tok_to_int64`, unified_datasets.py:218-222
-            out[self.names[f]] = t.pin_memory() if self.pin else t
+            arr = np.stack([b[f] for b in buf])
+            if arr.dtype == np.int16:            # 16-bit files hold ids up to 65535 (vocabulary 64000): reinterpret, do not sign-extend
+                arr = arr.view(np.uint16)
+            arr = arr.astype(np.int64)           # `tok_to_int64`, unified_datasets.py:218-222
+            name = self.names[f]
+            lo, hi = int(arr.min()), int(arr.max())
+            V = self.vocab.get(name)
+            if lo < 0 or (V is not None and hi >= V):
+                # nn.Embedding raises an index error in the reference; here ids index device tables directly
+                raise ValueError(f"TokenShards: modality {name}: token ids in [{lo}, {hi}] outside [0, {V if V is not None else 'inf'})")
+            t = torch.from_numpy(arr)
+            out[name] = t.pin_memory() if self.pin else t
         return out

@@ -280,13 +280,22 @@ def masking_budgets_host(cfg: ModelCfg, batch: int, n_in_range=(2048, 2048), n_t
     k_in = np.zeros((n, batch), dtype=np.int64)
     k_tg = np.zeros((n, batch), dtype=np.int64)
 
+    f32_lo, f32_hi = np.float32(np.finfo(np.float32).tiny), np.nextafter(np.float32(1.0), np.float32(0.0))
+
+    def f32_sample(a):
+        # torch's Dirichlet.sample() on float32 concentrations (what masking.py:192 calls): gamma variates in double,
+        # normalised, cast to float32 and CLAMPED to [FLT_MIN, 1 - 2^-24] (ATen _s_dirichlet).  The clamp is part of the
+        # reference's law: a one-hot draw is never exactly 1, so floor(p * N) leaves one token over, which the arg-max of
+        # the next draw hands to (3 times out of 4) ANOTHER modality - pinned by tests/golden/budget_stats.npz
+        return np.clip(rng.dirichlet(a).astype(np.float32), f32_lo, f32_hi)
+
     def draw(alpha, total, cap):
         a = np.full(n, max(alpha, 1e-9))
         bud = np.zeros(n, dtype=np.int64)
         for _ in range(max_tries):
-            bud = np.floor(rng.dirichlet(a) * total).astype(np.int64)
+            bud = np.floor(f32_sample(a) * np.float32(total)).astype(np.int64)
             for _ in range(int(total - bud.sum())):
-                bud[int(np.argmax(rng.dirichlet(a)))] += 1
+                bud[int(np.argmax(f32_sample(a)))] += 1
             bud = np.minimum(bud, cap)
             if (bud >= min_tokens).all():
                 break

@@ -27,6 +27,7 @@ class TrainStep:
         self.opt = FusedAdamW(engine, lr=lr, weight_decay=weight_decay, world_size=world_size)
         self.clip = clip_grad
         self.sparse = None
+        self.clips_per_step = clips_per_step
         skip = ()
         if (world_size > 1 or force_reducer) and sparse_tables != "off" and clips_per_step is not None:
             cap = clips_per_step * engine.N
@@ -51,6 +52,11 @@ class TrainStep:
         eng = self.engine
         names = [m.name for m in eng.mods]
         k = len(micro_batches)
+        if self.sparse is not None:
+            # the row lists are sized for clips_per_step clips: more would drop touched rows from the exchange (replicas diverge)
+            total = sum(next(iter(mb.values()))["input_mask"].shape[0] for mb in micro_batches)
+            if total > self.clips_per_step:
+                raise ValueError(f"TrainStep: {total} clips in this step, sparse table exchange sized for clips_per_step={self.clips_per_step}")
         self.loss_sum.zero_()
         for i, mb in enumerate(micro_batches):
             order = self.rng.sample(names, len(names))

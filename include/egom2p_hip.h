@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 1
+/* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
+ * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; loaders must refuse other versions) */
+#define EGO_ABI_VERSION 2
 #define EGO_MAX_MODS 8
 
 /* GEMM epilogues */

@@ -7,7 +7,7 @@ come from the counter-based generator.  Per schedule step the fixture holds the 
 statistics of the conditional / unconditional logits, and the tokens the reference sampled (teacher forcing
 for the next step).
 
-    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768 | gen_rgb2cam_b768 | gen_rgb2gaze_b768 | gen_depth2rgb_b768]
+    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768 | gen_rgb2depth_b12 | gen_rgb2cam_b768 | gen_rgb2gaze_b768 | gen_depth2rgb_b768]
 """
 from __future__ import annotations
 
@@ -56,6 +56,9 @@ def main():
         "gen_rgb2cam_b768": ("ego_b_2e_2d", 23, True, "tok_rgb", "tok_cam", 30, 3),          # eval_model_rgb2cam.py:46-60
         "gen_rgb2gaze_b768": ("ego_b_2e_2d", 24, True, "tok_rgb", "tok_gaze", 30, 5),        # eval_model_rgb2gaze.py:47-61
         "gen_depth2rgb_b768": ("ego_b_2e_2d", 25, True, "tok_depth", "tok_rgb", 5120, 6),    # eval_model_depth2rgb.py:40-54
+        # FULL-DEPTH config 4: the registered 12e/12d ego-b (400 M), rgb -> depth, N = 5120 / 6827 / 8534 encoder tokens on the
+        # conditional passes and 0 / 1707 / 3414 on the unconditional ones (generate.py:785-817, 1031)
+        "gen_rgb2depth_b12": ("egom2p_base_12e_12d_swiglu_nobias", 26, True, "tok_rgb", "tok_depth", 5120, 3),
     }
     cfg_name, seed, peaked, cond, target_mod, n_target, n_steps = TASKS[which]
     cfg = MODEL_CFGS[cfg_name]

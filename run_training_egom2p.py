@@ -136,9 +136,11 @@ class ShardClips:
     def __init__(self, args, model, epoch, rank, world, steps, seed, device):
         from egom2p_amd.data import TokenShards
         from egom2p_amd.masking import UnifiedMasking
-        self.ds = TokenShards(args.data_path, args.batch_size, rank=rank, world=world, shuffle_seed=seed)
-        self.ds.set_epoch(epoch)
         info = {m: MODALITY_INFO[m] for m in args.in_domains}
+        # the shard shuffle must be the same on every rank (it is dealt rank::world afterwards): args.seed, not seed + rank
+        self.ds = TokenShards(args.data_path, args.batch_size, rank=rank, world=world, shuffle_seed=args.seed,
+                              vocab={m: int(i["vocab_size"]) for m, i in info.items()})
+        self.ds.set_epoch(epoch)
         missing = set(info) - set(self.ds.names.values())
         if missing:
             raise ValueError(f"--data_path has no folder for {sorted(missing)} (folders: {self.ds.folders})")
@@ -149,9 +151,7 @@ class ShardClips:
         return self.steps
 
     def __iter__(self):
-        for i, batch in enumerate(self.ds):
-            if i >= self.steps:
-                break
+        for batch in self.ds.batches(self.steps):     # the same step count on every rank (cycles over the rank's shards)
             yield self.mask({k: v.to(self.device, non_blocking=True) for k, v in batch.items() if k in self.mask.names})
 
 
@@ -190,6 +190,8 @@ def train_one_epoch(model, loader, optimizer, scaler, args, epoch, start_steps, 
         if args.max_steps > 0 and step + 1 >= args.max_steps:
             break
     torch.cuda.synchronize()
+    if seen == 0:
+        raise RuntimeError("train_one_epoch: the loader produced no batch")
     return {"loss": loss.item(), "clips_per_s": seen / (time.time() - t0)}
 
 
@@ -237,6 +239,9 @@ def main(args):
         if rank == 0:
             print(f"resumed {args.resume}: continuing at epoch {first_epoch}, optimiser step {start}", flush=True)
     for epoch in range(first_epoch, epochs):
+        # the decoder-modality shuffle draws from python's global `random` (egom2p_model.py:312): one stream per
+        # (seed, epoch), so a resumed run continues with the orders an uninterrupted run would have drawn
+        random.seed(seed * 1000 + epoch)
         if args.data_path:
             loader = ShardClips(args, model.module, epoch, rank, world, steps_per_epoch, seed, device)
         else:

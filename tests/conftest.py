@@ -22,7 +22,7 @@ def load_golden(case):
     if not os.path.exists(path):
         pytest.skip(f"golden fixture {case}.npz not present")
     g = np.load(path, allow_pickle=False)
-    meta = ast.literal_eval(str(g["meta"]))
+    meta = ast.literal_eval(str(g["meta"])) if "meta" in g.files else {}
     if "budgets" in meta:
         meta["budgets"] = ast.literal_eval(meta["budgets"])
     return g, meta

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (ego_\w+)", out))
     assert _declared() <= exported
-    assert lib.ego_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "egom2p_hip.h")).read()
+    assert lib.ego_abi_version() == L.ABI_VERSION == int(re.search(r"#define EGO_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_no_oracle_import_in_product_path():

@@ -88,3 +88,44 @@ def test_directory_layout(tmp_path):
             np.savez(tmp_path / f / "setB" / f"s{i:02d}.npz", np.full(30, i, np.int32))
     got = list(TokenShards(str(tmp_path), batch_size=3, modalities=["cam", "gaze"], pin_memory=False))
     assert len(got) == 2 and torch.equal(got[1]["tok_gaze"][:, 0], torch.tensor([3, 4, 5]))
+
+
+def test_two_ranks_uneven_shards_are_disjoint_and_step_matched(tmp_path):
+    """with a rank-independent shuffle seed the two ranks' shards are a partition of the set (5 shards: 3 + 2),
+    and `batches(steps)` yields the same number of batches on both ranks although their shares differ."""
+    folders = ["rgb", "cam"]
+    shape = {"rgb": (5, 32, 32), "cam": (30,)}
+    truth = _write(str(tmp_path), folders, n_shards=5, per_shard=4, shape_of=shape)
+    path = f"{tmp_path}/[rgb,cam]/setA/token/shard-{{000000..000004}}.tar"
+    per_rank = []
+    for r in range(2):
+        ds = TokenShards(path, batch_size=2, rank=r, world=2, shuffle_seed=7, pin_memory=False, vocab={"tok_rgb": 64000, "tok_cam": 256})
+        ds.set_epoch(3)
+        one_pass = [int(x.sum()) for b in ds for x in b["tok_cam"]]
+        per_rank.append(one_pass)
+        assert len(list(ds.batches(9))) == 9                        # more steps than the smaller share holds (2 shards = 4 batches)
+        assert ds.epoch == 3
+    assert len(per_rank[0]) == 12 and len(per_rank[1]) == 8         # 3 shards vs 2 shards of 4 samples
+    want = sorted(int(v.sum()) for (f, k), v in truth.items() if f == "cam")
+    assert sorted(per_rank[0] + per_rank[1]) == want                # disjoint and complete
+    # different seeds per rank (what run_training passed before) would NOT be a partition - the reason for the rule
+    a = [int(x.sum()) for b in TokenShards(path, 2, rank=0, world=2, shuffle_seed=1, pin_memory=False) for x in b["tok_cam"]]
+    b = [int(x.sum()) for b in TokenShards(path, 2, rank=1, world=2, shuffle_seed=2, pin_memory=False) for x in b["tok_cam"]]
+    assert sorted(a + b) != want
+
+
+def test_out_of_range_and_16_bit_token_ids(tmp_path):
+    """Token ids index device tables directly: ids outside [0, vocab) raise on the host (the reference's nn.Embedding raises);
+    int16 files are read as unsigned 16-bit (ids up to 63999 do not fit int16)."""
+    root = str(tmp_path)
+    for f, arr in (("rgb", np.full((5, 32, 32), 63999, np.uint16).view(np.int16)), ("cam", np.arange(30, dtype=np.int16))):
+        os.makedirs(os.path.join(root, f), exist_ok=True)
+        for i in range(2):
+            np.savez(os.path.join(root, f, f"k{i}.npz"), arr)
+    b = next(iter(TokenShards(root, 2, modalities=["rgb", "cam"], pin_memory=False, vocab={"tok_rgb": 64000, "tok_cam": 256})))
+    assert int(b["tok_rgb"].max()) == 63999 and int(b["tok_rgb"].min()) == 63999
+    with pytest.raises(ValueError, match="tok_cam"):
+        next(iter(TokenShards(root, 2, modalities=["rgb", "cam"], pin_memory=False, vocab={"tok_rgb": 64000, "tok_cam": 16})))
+    np.savez(os.path.join(root, "cam", "k1.npz"), np.full(30, -3, np.int32))
+    with pytest.raises(ValueError, match="tok_cam"):
+        next(iter(TokenShards(root, 2, modalities=["rgb", "cam"], pin_memory=False)))

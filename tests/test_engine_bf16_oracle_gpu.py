@@ -30,7 +30,9 @@ SENS_FACTOR = 2.5       # a gradient may differ from the bf16 oracle by 2.5 x th
 LOSS_TOL = 3e-4
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged"])
+# b12 = the registered full-depth ego-b (12e / 12d, 400 M parameters), L2 = ego-L width (D = 1152): three oracle passes of
+# one clip each (about a minute on the box's 16 host cores) - the full-size cases sit behind the tight bars too
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b12", "L2"])
 def test_engine_matches_bf16_mode_oracle(case):
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]

@@ -98,6 +98,35 @@ def test_engine_matches_reference(case):
         r = float(g[f"mod_loss.{m.name}"])
         assert abs(mod_loss[m.name].item() - r) < LOSS_RTOL * max(abs(r), 1.0), (m.name, mod_loss[m.name].item(), r)
 
+    # ---- training-path logits (forward_mod_loss's `forward_logits(y[decoder_mod_mask == id])`, egom2p_model.py:633-636): the
+    # fixture holds the first 4 rows x 16 columns and the arg-max of the first 64 rows of every modality, in (clip, decoder
+    # position) order - the modality-grouped order of the engine's decoder_norm output (ranges[c] = first row, row count)
+    rng_h = eng.ranges.cpu().numpy()
+    dmm = torch.from_numpy(g["dec_mod_mask"].astype(np.int64)).cuda().view(-1)
+    for c, m in enumerate(cfg.mods):
+        ref_head, ref_am = g[f"logits_head.{m.name}"], g[f"logits_argmax.{m.name}"]
+        sel = (dmm == m.id).nonzero()[:, 0]                     # (clip, decoder position) order = y[decoder_mod_mask == id]
+        cnt = int(sel.numel())
+        assert cnt == int(rng_h[c, 1]) and ref_am.shape[0] == min(64, cnt)
+        if cnt == 0:
+            continue
+        rows = min(64, cnt)
+        src = eng.perm[:RM].long()[sel[:rows]]                  # where the final LayerNorm wrote those rows (modality-grouped)
+        assert int(src.min()) >= int(rng_h[c, 0]) and int(src.max()) < int(rng_h[c, 0]) + cnt
+        l = eng.lin[eng.logit_key[m.name]]
+        lg = torch.empty(rows, m.vocab_size, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt(eng.yn[src].contiguous(), l.wb, lg, rows, m.vocab_size, D, 0, lda=D, ldb=D, ldc=m.vocab_size)
+        lg = lg.float()
+        assert rel_l2(lg[:ref_head.shape[0], :16].cpu().numpy(), ref_head) < 3e-2, m.name
+        ref_am_t = torch.from_numpy(ref_am.astype(np.int64)).cuda()
+        mism = lg.argmax(-1) != ref_am_t
+        # a differing arg-max must be a proven near-tie: in OUR logits the reference's token is within the accepted logit
+        # error (3e-2 of the row's largest |logit|) of the row maximum (random-init heads are nearly flat over 64,000 tokens)
+        if mism.any():
+            gap = (lg.max(-1).values - lg.gather(1, ref_am_t[:, None])[:, 0])[mism]
+            assert bool((gap <= 3e-2 * lg.abs().max(-1).values[mism]).all()), (m.name, gap.max().item())
+        assert 1.0 - mism.float().mean().item() >= (0.98 if m.vocab_size <= 256 else 0.75), (m.name, mism.float().mean().item())
+
     # ---- backward + clip + AdamW
     eng.zero_grad()
     eng.backward(1.0)

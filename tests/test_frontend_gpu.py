@@ -154,6 +154,23 @@ def test_clip_synth_on_device_is_bit_identical_to_host():
                 assert torch.equal(dev[m.name][k].cpu(), host[m.name][k]), (m.name, k)
 
 
+@pytest.mark.parametrize("case", ["fixed", "ranged"])
+def test_device_budget_sampler_follows_the_reference_draws(case):
+    """SURVEY section 8 row f4, pinned to the reference: `ego_budget_dirichlet` against 24,000 draws of the REAL
+    `UnifiedMasking.input_token_budget` / `target_token_budget` (tests/golden/budget_stats.npz, made by
+    oracle/make_goldens_masking.py): per-draw invariants, means / deviations / P(0) / P(cap) / one-hot share and the
+    Kolmogorov-Smirnov distance per modality, for fixed (2048 / 2048) and ranged token counts (bars: tests/_budget_check.py)."""
+    from conftest import load_golden
+    from _budget_check import check_against_reference
+    g, _ = load_golden("budget_stats")
+    cfg = MODEL_CFGS["egom2p_base_12e_12d_swiglu_nobias"]
+    (lo_i, hi_i), (lo_t, hi_t) = g[f"{case}.range"]
+    k_in, k_tg = synth.masking_budgets_device(cfg, 24000, (int(lo_i), int(hi_i)), (int(lo_t), int(hi_t)), seed=13)
+    torch.cuda.synchronize()
+    rep = check_against_reference(g, case, k_in.cpu().numpy(), k_tg.cpu().numpy())
+    print(case, {k: np.round(v["ks"], 4) for k, v in rep.items()})
+
+
 def test_device_budget_sampler_follows_the_reference_mixture():
     """the Dirichlet-mixture token budgets of `UnifiedMasking` (masking.py:181-234, :530-541)
     sampled on the device.  Checked against the host restatement of the same algorithm (independent random stream):

@@ -81,7 +81,7 @@ def test_schedule_matches_reference():
     assert all(s["cfg_cond_domains"] == ["tok_rgb"] and s["cfg_scale"] == 2.0 and s["temperature"] == 0.01 for s in sch)
 
 
-@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768", "gen_rgb2cam_b768", "gen_rgb2gaze_b768", "gen_depth2rgb_b768"])
+@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768", "gen_rgb2depth_b12", "gen_rgb2cam_b768", "gen_rgb2gaze_b768", "gen_depth2rgb_b768"])
 def test_roar_cfg_generation_matches_reference(fixture):
     """gen_rgb2depth: D = 384 with a random-init (flat) head - near-ties decide most tokens, so the bars are on the logits.
     The *_b768 fixtures: ego-b width (D = 768, 12 heads) with a PEAKED target head (synth.peak_logit_table): arg-max and sampled

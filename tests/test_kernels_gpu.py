@@ -29,7 +29,7 @@ def _seed():
 
 
 def test_library_loads():
-    assert L.load().ego_abi_version() == 1
+    assert L.load().ego_abi_version() == L.ABI_VERSION
 
 
 # ------------------------------------------------------------------------------------------ GEMM NT
