@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOM2P_HIP_LIB", os.path.join(_HERE, "libegom2p_hip.so"))   # override: kernel experiments
 MAX_MODS = 8
 
-ABI_VERSION = 2          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
+ABI_VERSION = 3          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
 EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -50,6 +50,7 @@ class EmbedBwdDesc(C.Structure):
     _fields_ = [
         ("dtable", vp * MAX_MODS), ("dmod", vp * MAX_MODS), ("dbase", vp), ("dx", vp), ("d2", vp),
         ("slot", vp), ("tok", vp), ("rows", i64), ("D", i32), ("n_mods", i32), ("touched", vp * MAX_MODS),
+        ("work", vp), ("work_floats", i64),
     ]
 
 
@@ -58,13 +59,15 @@ _SIGS = {
     "ego_gemm_kernel_mode": [i32, i32],
     "ego_compact": [C.POINTER(CompactDesc), i32, vp],
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
+    "ego_embed_bwd_work_floats": [i64, i32, i32],
     "ego_embed_bwd": [C.POINTER(EmbedBwdDesc), vp],
     "ego_rows_compact": [vp, i32, i32, vp, vp, vp],
     "ego_rows_gather": [vp, vp, vp, i32, i32, vp, vp],
     "ego_rows_scatter": [vp, vp, vp, i32, i32, vp, i32, vp],
     "ego_loss_perm": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i64, vp, vp],
-    "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "ego_layernorm_bwd_work_floats": [i32, i32],
+    "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "ego_quant_fp8_rows": [vp, i64, i64, i32, vp, i64, vp, vp],
@@ -86,7 +89,8 @@ _SIGS = {
     "ego_loss_finalize": [vp, vp, i32, vp, vp, vp],
     "ego_cast_weight": [vp, i32, i32, i64, vp, i64, vp, i64, i32, vp],
     "ego_cast_f32_bf16": [vp, vp, i64, vp],
-    "ego_bias_grad": [vp, i64, i32, vp, vp],
+    "ego_bias_grad_work_floats": [i64, i32],
+    "ego_bias_grad": [vp, i64, i32, vp, vp, i64, vp],
     "ego_grad_sqnorm": [vp, i64, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
     "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
@@ -118,7 +122,7 @@ def load():
         for name, args in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = i32
+            fn.restype = i64 if name.endswith("_work_floats") else i32
         if lib.ego_abi_version() != ABI_VERSION:
             raise EgoHipError(f"libegom2p_hip.so ABI version {lib.ego_abi_version()} != binding {ABI_VERSION}: rebuild (make -C egom2p_amd/csrc)")
         # kernel experiments: EGO_GEMM_NT256 / EGO_GEMM_TN256 = 0 | 1 | 2 pick the GEMM tile family (the library itself

@@ -112,3 +112,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// Ordered column sums of per-workgroup partial rows (rowops.hip): dst.p[c / seg][c % seg] += sum_r parts[r][c], rows summed
+// in index order, so gradients reduced this way are bitwise reproducible (no float atomics).  `parts` must have room for
+// colsum_work_floats(n, W) floats (the partial rows followed by the intermediate levels).
+#ifndef EGO_MAX_MODS
+#define EGO_MAX_MODS 8
+#endif
+struct ColsumDst { float* p[EGO_MAX_MODS + 1]; int seg; };
+int colsum_launch(float* parts, long n, int W, const ColsumDst& dst, hipStream_t stream);
+long colsum_work_floats(long n, int W);

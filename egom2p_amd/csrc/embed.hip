@@ -266,7 +266,18 @@ __global__ __launch_bounds__(256) void loss_perm_kernel(const int* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // embedding backward: table[slot][tok] += dx row ; dmod[slot] += (dx + d2) row ; dbase += dx row.
-// 64 rows per workgroup; modality sums are combined in LDS, then one atomic per column per workgroup.
+//
+// No float atomics - every sum is taken in an order that depends on the data only, so the gradients are bitwise
+// reproducible (and the table scatter no longer runs at the ~1.3 TB/s atomic rate of the chip):
+//   * embed_sums_kernel: modality / base column sums.  A wave walks 32 consecutive rows and keeps the sum of the CURRENT
+//     slot in registers (kept rows come in runs of one modality); on a slot change it adds the run into its own LDS
+//     rows.  The 4 waves' rows are combined in wave order into ONE partial row per workgroup, plain stores; the sum over
+//     workgroups is colsum_kernel's ordered reduction.
+//   * embed_tables_kernel: the table scatter as a gather.  Workgroup j owns the table rows with token id = j (mod ET_WGS):
+//     it scans the (slot, token) keys of all rows, collects its own in ROW ORDER (ballot + prefix positions), ranks them by
+//     (key, position) and sums every key's dx rows in ascending row order into the table row (one owner per table row:
+//     plain read-modify-write).  Keys with 64 or more rows are summed by the 4 waves in contiguous quarters and joined in
+//     wave order.
 // ---------------------------------------------------------------------------------------------
 struct EmbedBwdArgs {
     float* dtable[EGO_MAX_MODS];   // [V, D] grads or null
@@ -276,52 +287,211 @@ struct EmbedBwdArgs {
     const int* slot; const int* tok;
     long rows; int D, n_mods;
     unsigned char* touched[EGO_MAX_MODS];   // optional [V]: set to 1 for every table row that receives a gradient
+    float* part;                   // [workgroups][(n_mods + 1) * D] partial column sums
 };
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lsum[];   // [(n_mods + 1)][D]
+constexpr int ES_ROWS = 128;       // rows per workgroup of embed_sums_kernel (32 per wave)
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void embed_sums_kernel(EmbedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lsum[];   // [4 waves][(n_mods + 1)][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nsl = a.n_mods + 1;
-    for (int i = threadIdx.x; i < nsl * a.D; i += 256) lsum[i] = 0.f;
-    __syncthreads();
-    for (int rr = 0; rr < 16; ++rr) {
-        const long row = (long)blockIdx.x * 64 + rr * 4 + wave;
+    const int nsl = a.n_mods + 1, W = nsl * a.D, nc = a.D >> 2;
+    float* mine = lsum + wave * W;
+    for (int i = lane; i < W; i += 64) mine[i] = 0.f;
+    f32x4 acc[MAXC], accb[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[i] = acc[i]; }
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                f32x4* d = (f32x4*)(mine + cur * a.D + c * 4);
+                *d += acc[i];
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    const long r0 = (long)blockIdx.x * ES_ROWS + wave * 32;
+    for (int rr = 0; rr < 32; ++rr) {
+        const long row = r0 + rr;
         if (row >= a.rows) break;
         const int s = a.slot[row];
         if (s < 0) continue;
-        float* trow = nullptr;
+        if (s != cur) { flush(); cur = s; }
 #pragma unroll
-        for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) trow = a.dtable[m];
-        if (trow) {
-            trow += (long)a.tok[row] * a.D;
-            unsigned char* fl = nullptr;
-#pragma unroll
-            for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) fl = a.touched[m];
-            if (fl && lane == 0) fl[a.tok[row]] = 1;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                f32x4 g = *(const f32x4*)(a.dx + row * a.D + c * 4);
+                if (a.dbase) accb[i] += g;
+                if (a.d2) g += *(const f32x4*)(a.d2 + row * a.D + c * 4);
+                acc[i] += g;
+            }
         }
-        // one dword per lane, 256 contiguous bytes per wave instruction: the shape global float
-        // atomics run at full rate with
-        for (int col = lane; col < a.D; col += 64) {
-            float g = a.dx[row * a.D + col];
-            if (trow) atomicAdd(trow + col, g);
-            if (a.dbase) atomicAdd(&lsum[a.n_mods * a.D + col], g);
-            if (a.d2) g += a.d2[row * a.D + col];
-            atomicAdd(&lsum[s * a.D + col], g);
+    }
+    flush();
+    if (a.dbase) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) *(f32x4*)(mine + a.n_mods * a.D + c * 4) = accb[i];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nsl * a.D; i += 256) {
-        const int s = i / a.D, col = i % a.D;
-        const float v = lsum[i];
-        if (v == 0.f) continue;
-        float* dst = nullptr;
-        if (s == a.n_mods) dst = a.dbase;
-        else {
+    for (int i = threadIdx.x; i < W; i += 256)
+        a.part[(long)blockIdx.x * W + i] = ((lsum[i] + lsum[W + i]) + lsum[2 * W + i]) + lsum[3 * W + i];
+}
+
+constexpr int ET_WGS = 512;        // owners of the table rows (token id mod ET_WGS)
+constexpr int ET_CAP = 2048;       // (key, row) pairs a workgroup holds between two flushes
+constexpr int ET_HEAVY = 64;       // keys with at least this many rows are summed by the whole workgroup
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void embed_tables_kernel(EmbedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char et_sm[];
+    int* lkey = (int*)et_sm;                  // [ET_CAP] collected in row order
+    int* lrow = lkey + ET_CAP;
+    int* skey = lrow + ET_CAP;                // [ET_CAP] sorted by (key, position)
+    int* srow = skey + ET_CAP;
+    int* heads = srow + ET_CAP;               // [ET_CAP] start positions of the keys' runs in skey / srow
+    int* wcnt = heads + ET_CAP;               // [8]: per-wave match counts, number of heads
+    float* comb = (float*)(wcnt + 8);         // [4][D] partial sums of a heavy key
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, nc = a.D >> 2;
+    int n = 0;                                 // pairs collected (uniform)
+
+    auto sum_rows = [&](const int* rows_, int cnt, f32x4 (&acc)[MAXC]) {     // ascending positions, one wave
 #pragma unroll
-            for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) dst = a.dmod[m];
+        for (int i = 0; i < MAXC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int q = 0;
+        for (; q + 4 <= cnt; q += 4) {
+            f32x4 v[4][MAXC];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* src = a.dx + (long)rows_[q + k] * a.D;
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < nc) v[k][i] = *(const f32x4*)(src + c * 4); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < nc) acc[i] += v[k][i]; }
         }
-        if (dst) atomicAdd(dst + col, v);
+        for (; q < cnt; ++q) {
+            const float* src = a.dx + (long)rows_[q] * a.D;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < nc) acc[i] += *(const f32x4*)(src + c * 4); }
+        }
+    };
+    auto table_row = [&](int key, unsigned char*& fl) -> float* {
+        const int s = key >> 16, t = key & 0xffff;
+        float* tb = nullptr;
+        fl = nullptr;
+#pragma unroll
+        for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) { tb = a.dtable[m]; fl = a.touched[m]; }
+        if (fl) fl += t;
+        return tb + (long)t * a.D;
+    };
+
+    auto flush = [&]() {
+        __syncthreads();
+        // rank by (key, position): stable, so every key's rows stay in ascending row order
+        for (int i = tid; i < n; i += 256) {
+            const int k = lkey[i];
+            int rank = 0;
+            for (int e = 0; e < n; ++e) { const int ke = lkey[e]; rank += (ke < k) || (ke == k && e < i); }
+            skey[rank] = k; srow[rank] = lrow[i];
+        }
+        if (tid == 0) wcnt[4] = 0;
+        __syncthreads();
+        // run heads in ascending order: every 256-block of positions appends its heads behind the previous blocks'
+        for (int base = 0; base < n; base += 256) {
+            const int i = base + tid;
+            const bool head = i < n && (i == 0 || skey[i] != skey[i - 1]);
+            const unsigned long long m = __ballot(head);
+            if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+            __syncthreads();
+            int off = wcnt[4];
+            for (int w = 0; w < wave; ++w) off += wcnt[w];
+            if (head) heads[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+            if (tid == 0) wcnt[4] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        const int nh = wcnt[4];
+        // light keys: wave w takes runs w, w + 4, ...
+        for (int h = wave; h < nh; h += 4) {
+            const int p0 = heads[h], p1 = (h + 1 < nh) ? heads[h + 1] : n;
+            if (p1 - p0 >= ET_HEAVY) continue;
+            f32x4 acc[MAXC];
+            sum_rows(srow + p0, p1 - p0, acc);
+            unsigned char* fl;
+            float* dst = table_row(skey[p0], fl);
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < nc) *(f32x4*)(dst + c * 4) += acc[i]; }
+            if (fl && lane == 0) *fl = 1;
+        }
+        // heavy keys: the four waves sum contiguous quarters, wave 0 joins them in wave order
+        for (int h = 0; h < nh; ++h) {
+            const int p0 = heads[h], p1 = (h + 1 < nh) ? heads[h + 1] : n, cnt = p1 - p0;
+            if (cnt < ET_HEAVY) continue;
+            __syncthreads();
+            const int q = (cnt + 3) / 4, b0 = min(cnt, wave * q), b1 = min(cnt, b0 + q);
+            f32x4 acc[MAXC];
+            sum_rows(srow + p0 + b0, b1 - b0, acc);
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < nc) *(f32x4*)(comb + wave * a.D + c * 4) = acc[i]; }
+            __syncthreads();
+            if (wave == 0) {
+                unsigned char* fl;
+                float* dst = table_row(skey[p0], fl);
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nc) {
+                        const f32x4 t = ((*(const f32x4*)(comb + c * 4) + *(const f32x4*)(comb + a.D + c * 4)) +
+                                         *(const f32x4*)(comb + 2 * a.D + c * 4)) + *(const f32x4*)(comb + 3 * a.D + c * 4);
+                        *(f32x4*)(dst + c * 4) += t;
+                    }
+                }
+                if (fl && lane == 0) *fl = 1;
+            }
+        }
+        __syncthreads();
+        n = 0;
+    };
+
+    for (long base = 0; base < a.rows; base += 256) {
+        const long r = base + tid;
+        int key = -1;
+        if (r < a.rows) {
+            const int s = a.slot[r];
+            if (s >= 0) {
+                bool has = false;
+#pragma unroll
+                for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) has = a.dtable[m] != nullptr;
+                const int t = a.tok[r];
+                if (has && (t & (ET_WGS - 1)) == j) key = (s << 16) | t;
+            }
+        }
+        const unsigned long long m = __ballot(key >= 0);
+        if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = n;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        if (key >= 0) {
+            const int pos = off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            lkey[pos] = key; lrow[pos] = (int)r;
+        }
+        n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+        if (n > ET_CAP - 256) flush();
     }
+    if (n > 0) flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,16 +625,43 @@ extern "C" int ego_loss_perm(const int* seg, const int* canon, const int* slot, 
     return EGO_OK;
 }
 
+extern "C" long ego_embed_bwd_work_floats(long rows, int D, int n_mods) {
+    return colsum_work_floats((rows + ES_ROWS - 1) / ES_ROWS, (n_mods + 1) * D);
+}
+
 extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
-    if (!d || d->rows <= 0 || d->D % 4 || d->n_mods <= 0 || d->n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
+    if (!d || d->rows <= 0 || d->D % 4 || d->D > 2048 || d->n_mods <= 0 || d->n_mods > EGO_MAX_MODS || d->rows > 0x7fffffffL) return EGO_ERR_ARG;
+    if (!d->work || d->work_floats < ego_embed_bwd_work_floats(d->rows, d->D, d->n_mods)) return EGO_ERR_ARG;
     EmbedBwdArgs a{};
-    for (int m = 0; m < EGO_MAX_MODS; ++m) { a.dtable[m] = d->dtable[m]; a.dmod[m] = d->dmod[m]; }
+    bool tables = false;
+    for (int m = 0; m < EGO_MAX_MODS; ++m) { a.dtable[m] = d->dtable[m]; a.dmod[m] = d->dmod[m]; tables |= d->dtable[m] != nullptr; }
     a.dbase = d->dbase; a.dx = d->dx; a.d2 = d->d2; a.slot = d->slot; a.tok = d->tok;
     a.rows = d->rows; a.D = d->D; a.n_mods = d->n_mods;
     for (int m = 0; m < EGO_MAX_MODS; ++m) a.touched[m] = d->touched[m];
-    const size_t lds = (size_t)(d->n_mods + 1) * d->D * sizeof(float);
-    if (lds > 64 * 1024) return EGO_ERR_ARG;
-    EGO_LAUNCH(embed_bwd_kernel, dim3((unsigned)((d->rows + 63) / 64)), dim3(256), lds, stream, a);
+    a.part = d->work;
+    const int W = (d->n_mods + 1) * d->D;
+    const size_t lds = (size_t)4 * W * sizeof(float);
+    if (lds > 160 * 1024) return EGO_ERR_ARG;
+    const long nwg = (d->rows + ES_ROWS - 1) / ES_ROWS;
+#define ES_GO(C) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)embed_sums_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                      EGO_LAUNCH(embed_sums_kernel<C>, dim3((unsigned)nwg), dim3(256), lds, stream, a); } while (0)
+    if (d->D <= 768) ES_GO(3); else if (d->D <= 1024) ES_GO(4); else if (d->D <= 1536) ES_GO(6); else ES_GO(8);
+#undef ES_GO
     LAUNCH_CHECK();
+    ColsumDst dst{};
+    for (int m = 0; m < d->n_mods; ++m) dst.p[m] = d->dmod[m];
+    dst.p[d->n_mods] = d->dbase;
+    dst.seg = d->D;
+    colsum_launch(d->work, nwg, W, dst, stream);
+    LAUNCH_CHECK();
+    if (tables) {
+        // table ids index 16-bit key fields: vocabularies up to 65536 (the reference's largest is 64000)
+        const size_t lds2 = (size_t)(5 * ET_CAP + 8) * sizeof(int) + (size_t)4 * d->D * sizeof(float);
+#define ET_GO(C) do { (void)hipFuncSetAttribute((const void*)embed_tables_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+                      EGO_LAUNCH(embed_tables_kernel<C>, dim3(ET_WGS), dim3(256), lds2, stream, a); } while (0)
+        if (d->D <= 768) ET_GO(3); else if (d->D <= 1024) ET_GO(4); else if (d->D <= 1536) ET_GO(6); else ET_GO(8);
+#undef ET_GO
+        LAUNCH_CHECK();
+    }
     return EGO_OK;
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ w,
                                                      const float* dx_in, float* dx_out, bf16_t* dx_bf16,
-                                                     float* __restrict__ dw, int rows, int D) {
+                                                     float* __restrict__ dw_part, int rows, int D) {
     __shared__ float red[4][LN_MAXC * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = D >> 2;
@@ -152,8 +152,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         if (c < nc) *(f32x4*)(&red[wave][c * 4]) = dwa[i];
     }
     __syncthreads();
+    // one partial row per workgroup, plain stores (no float atomics: the sum over workgroups is taken in a fixed order by
+    // colsum_kernel, so the weight gradient is bitwise reproducible - and the 768 same-address atomics per workgroup are gone)
     for (int col = threadIdx.x; col < D; col += 256)
-        atomicAdd(dw + col, red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+        dw_part[(long)blockIdx.x * D + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ordered column sums of per-workgroup partial rows: out[c] (+)= sum_r parts[r][c], rows summed in index order (fixed
+// order -> bitwise reproducible).  Two launches: chunks of COLSUM_CHUNK rows -> one row per chunk, then those -> out.
+// `dst` routes column c of the LAST stage to dst.p[c / seg] + c % seg (several gradient vectors behind one slab).
+// ---------------------------------------------------------------------------------------------
+constexpr int COLSUM_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ parts, long n, int W, float* __restrict__ mid,
+                                                     ColsumDst dst, int last) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W) return;
+    const long r0 = (long)blockIdx.y * COLSUM_CHUNK, r1 = min(n, r0 + COLSUM_CHUNK);
+    float s = 0.f;
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = parts[(r + k) * W + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < r1; ++r) s += parts[r * W + c];
+    if (!last) { mid[(long)blockIdx.y * W + c] = s; return; }
+    float* o = dst.p[c / dst.seg];
+    if (o) o[c % dst.seg] += s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,9 +394,9 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __rest
 }
 
 // db[col] += sum_rows g[row][col]   (bf16 g, fp32 accumulate).  A workgroup owns 256 rows; a thread sums 8 adjacent columns
-// (one 16-byte load per row) of every (256 / (D / 8))-th row, the row groups are combined in LDS, one atomic per column
-// and workgroup.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ g, long rows, int D, float* __restrict__ db) {
+// (one 16-byte load per row) of every (256 / (D / 8))-th row, the row groups are combined in LDS, one partial row per
+// workgroup (no atomics: bitwise reproducible).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ g, long rows, int D, float* __restrict__ db_part) {
     extern __shared__ __attribute__((aligned(16))) float bg_sm[];      // [rgroups][D]
     const int nvec = D >> 3, rgroups = 256 / nvec;
     const int cv = threadIdx.x % nvec, rg = threadIdx.x / nvec;
@@ -388,7 +417,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
     for (int c = threadIdx.x; c < D; c += 256) {
         float s = 0.f;
         for (int q = 0; q < rgroups; ++q) s += bg_sm[q * D + c];
-        atomicAdd(db + c, s);
+        db_part[(long)blockIdx.x * D + c] = s;              // summed over workgroups in order by colsum_kernel
     }
 }
 
@@ -438,6 +467,25 @@ inline int grid_for(long total, int cap = 4096) { return (int)((total + 255) / 2
 
 }  // namespace
 
+// parts [n][W] -> dst (accumulating).  work = parts followed by room for the intermediate rows.
+__attribute__((visibility("hidden"))) int colsum_launch(float* parts, long n, int W, const ColsumDst& dst, hipStream_t stream) {
+    ColsumDst none{};
+    while (n > COLSUM_CHUNK) {
+        const long nc = (n + COLSUM_CHUNK - 1) / COLSUM_CHUNK;
+        float* mid = parts + n * W;
+        EGO_LAUNCH(colsum_kernel, dim3((W + 255) / 256, (unsigned)nc), dim3(256), 0, stream, parts, n, W, mid, none, 0);
+        parts = mid; n = nc;
+    }
+    EGO_LAUNCH(colsum_kernel, dim3((W + 255) / 256, 1), dim3(256), 0, stream, parts, n, W, (float*)nullptr, dst, 1);
+    return 0;
+}
+__attribute__((visibility("hidden"))) long colsum_work_floats(long n, int W) {     // parts + every intermediate level
+    long tot = 0;
+    while (true) { tot += n * W; if (n <= COLSUM_CHUNK) break; n = (n + COLSUM_CHUNK - 1) / COLSUM_CHUNK; }
+    return tot;
+}
+
+
 extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd,
                                  const int* out_row, int rows, int D, float eps, void* q8, long ldq, float* qscale,
                                  hipStream_t stream) {
@@ -451,15 +499,22 @@ extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float*
     return EGO_OK;
 }
 
+extern "C" long ego_layernorm_bwd_work_floats(int rows, int D) { return colsum_work_floats((rows + LNB_ROWS - 1) / LNB_ROWS, D); }
+
 extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float* x, const float* mean,
                                  const float* rstd, const float* w, const float* dx_in, float* dx_out,
-                                 void* dx_bf16, float* dw, int rows, int D, hipStream_t stream) {
+                                 void* dx_bf16, float* dw, float* work, long work_floats, int rows, int D, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D % 4 || D > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
-#define LN_BWD(C) EGO_LAUNCH(ln_bwd_kernel<C>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, stream, (const bf16_t*)dy, \
-                       dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, dw, rows, D)
+    if (D % 4 || D > LN_MAXC_MAX * 256 || !work || work_floats < ego_layernorm_bwd_work_floats(rows, D)) return EGO_ERR_ARG;
+    const int nwg = (rows + LNB_ROWS - 1) / LNB_ROWS;
+#define LN_BWD(C) EGO_LAUNCH(ln_bwd_kernel<C>, dim3(nwg), dim3(256), 0, stream, (const bf16_t*)dy, \
+                       dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, work, rows, D)
     if (D <= 768) LN_BWD(3); else if (D <= 1024) LN_BWD(4); else if (D <= 1536) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD
+    LAUNCH_CHECK();
+    ColsumDst dst{};
+    dst.p[0] = dw; dst.seg = D;
+    colsum_launch(work, nwg, D, dst, stream);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -522,12 +577,19 @@ extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods
     return EGO_OK;
 }
 
-extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, hipStream_t stream) {
+extern "C" long ego_bias_grad_work_floats(long rows, int D) { return colsum_work_floats((rows + 255) / 256, D); }
+
+extern "C" int ego_bias_grad(const void* g, long rows, int D, float* db, float* work, long work_floats, hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D % 8 || D > 2048 || (((uintptr_t)g) & 15)) return EGO_ERR_ARG;
+    if (D % 8 || D > 2048 || (((uintptr_t)g) & 15) || !work || work_floats < ego_bias_grad_work_floats(rows, D)) return EGO_ERR_ARG;
     const int rgroups = 256 / (D / 8);
-    EGO_LAUNCH(bias_grad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)rgroups * D * sizeof(float), stream,
-               (const bf16_t*)g, rows, D, db);
+    const long nwg = (rows + 255) / 256;
+    EGO_LAUNCH(bias_grad_kernel, dim3((unsigned)nwg), dim3(256), (size_t)rgroups * D * sizeof(float), stream,
+               (const bf16_t*)g, rows, D, work);
+    LAUNCH_CHECK();
+    ColsumDst dst{};
+    dst.p[0] = db; dst.seg = D;
+    colsum_launch(work, nwg, D, dst, stream);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -36,11 +36,25 @@ def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=N
                                      0 if q8 is None else q8.stride(-2), _p(qscale), _stream()), "ego_layernorm_fwd")
 
 
+_WORK = {}
+
+
+def _work(device, n_floats):
+    """Scratch for the atomic-free reductions (partial rows per workgroup + ordered column sums), one buffer per device,
+    reused by every call in stream order; grown on demand (training steps are not graph-captured)."""
+    buf = _WORK.get(device)
+    if buf is None or buf.numel() < n_floats:
+        buf = _WORK[device] = torch.empty(int(n_floats * 1.25) + 1024, device=device, dtype=torch.float32)
+    return buf
+
+
 def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
     _need_cuda(x)
     rows, D = x.shape
-    check(L.load().ego_layernorm_bwd(_p(dy), _p(dy_row), _p(x), _p(mean), _p(rstd), _p(w), _p(dx_in), _p(dx_out),
-                                     _p(dx_bf16), _p(dw), rows, D, _stream()), "ego_layernorm_bwd")
+    lib = L.load()
+    wk = _work(x.device, lib.ego_layernorm_bwd_work_floats(rows, D))
+    check(lib.ego_layernorm_bwd(_p(dy), _p(dy_row), _p(x), _p(mean), _p(rstd), _p(w), _p(dx_in), _p(dx_out),
+                                _p(dx_bf16), _p(dw), _p(wk), wk.numel(), rows, D, _stream()), "ego_layernorm_bwd")
 
 
 def gemm_nt(A, B, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None, m_range=None, lda=None, ldb=None, ldc=None, ldr=None):
@@ -201,7 +215,9 @@ def cast_f32_bf16(src, dst):
 
 
 def bias_grad(g, rows, D, db):
-    check(L.load().ego_bias_grad(_p(g), rows, D, _p(db), _stream()), "ego_bias_grad")
+    lib = L.load()
+    wk = _work(g.device, lib.ego_bias_grad_work_floats(rows, D))
+    check(lib.ego_bias_grad(_p(g), rows, D, _p(db), _p(wk), wk.numel(), _stream()), "ego_bias_grad")
 
 
 def grad_sqnorm(g, out):
@@ -252,7 +268,10 @@ def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D, touched=None):
     d.dx, d.d2 = dx.data_ptr(), _p(d2)
     d.slot, d.tok = slot.data_ptr(), tok.data_ptr()
     d.rows, d.D, d.n_mods = rows, D, len(dmods)
-    check(L.load().ego_embed_bwd(C.byref(d), _stream()), "ego_embed_bwd")
+    lib = L.load()
+    wk = _work(dx.device, lib.ego_embed_bwd_work_floats(rows, D, len(dmods)))
+    d.work, d.work_floats = wk.data_ptr(), wk.numel()
+    check(lib.ego_embed_bwd(C.byref(d), _stream()), "ego_embed_bwd")
 
 
 def rows_compact(touched, cap, rows, count):

@@ -22,8 +22,9 @@ extern "C" {
 #endif
 
 /* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
- * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; loaders must refuse other versions) */
-#define EGO_ABI_VERSION 2
+ * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; 3: round 3 gave ego_layernorm_bwd,
+ * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; loaders must refuse other versions) */
+#define EGO_ABI_VERSION 3
 #define EGO_MAX_MODS 8
 
 /* GEMM epilogues */
@@ -87,7 +88,11 @@ typedef struct {
     const int* slot; const int* tok;
     long rows; int D, n_mods;
     unsigned char* touched[EGO_MAX_MODS];   /* optional uint8 [V] per table: set to 1 for every row that got a gradient */
+    float* work; long work_floats;          /* scratch, at least ego_embed_bwd_work_floats(rows, D, n_mods) floats */
 } ego_embed_bwd_desc;
+/* No float atomics: column sums through per-workgroup partial rows + an ordered reduction, the table scatter as a gather by
+ * the table row's owner in ascending row order - results are bitwise reproducible.  Vocabularies up to 65536. */
+long ego_embed_bwd_work_floats(long rows, int D, int n_mods);
 int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream);
 
 /* Row lists for the sparse data-parallel exchange of an embedding table's gradient (replaces, for few clips per step,
@@ -113,10 +118,13 @@ int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* 
  * row also leaves as e4m3 bytes + scale, exactly what ego_quant_fp8_rows would make of y (operand of an fp8 GEMM). */
 int ego_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* mean, float* rstd, const int* out_row,
                       int rows, int D, float eps, void* q8, long ldq, float* qscale, hipStream_t stream);
-/* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row. */
+/* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row.  The weight gradient goes
+ * through one partial row per workgroup in `work` (>= ego_layernorm_bwd_work_floats(rows, D) floats) and an ordered
+ * reduction: no float atomics, bitwise reproducible. */
+long ego_layernorm_bwd_work_floats(int rows, int D);
 int ego_layernorm_bwd(const void* dy_bf16, const int* dy_row, const float* x, const float* mean, const float* rstd,
-                      const float* w, const float* dx_in, float* dx_out, void* dx_out_bf16, float* dw, int rows, int D,
-                      hipStream_t stream);
+                      const float* w, const float* dx_in, float* dx_out, void* dx_out_bf16, float* dw, float* work,
+                      long work_floats, int rows, int D, hipStream_t stream);
 
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 inputs, fp32 MFMA accumulate.  Replaces F.linear under
  * autocast(bf16) (egom2p_utils.py:141-169, 180-203, 215-242; decoder_embeddings.py:372-383, 489-500)
@@ -241,7 +249,9 @@ int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, fl
 int ego_cast_weight(const float* W, int rows, int cols, long ld_src, void* Wb, long ld_w, void* Wt, long ld_t,
                     int rows_dst, hipStream_t stream);
 int ego_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
-int ego_bias_grad(const void* g_bf16, long rows, int D, float* db, hipStream_t stream);
+/* db += column sums of g (the bias gradient of decoder_proj_context, egom2p_model.py:157); same partial-row scheme. */
+long ego_bias_grad_work_floats(long rows, int D);
+int ego_bias_grad(const void* g_bf16, long rows, int D, float* db, float* work, long work_floats, hipStream_t stream);
 
 /* clip_grad_norm_ + AdamW over flat buffers (egom2p/utils/native_scaler.py:28-43, optim_factory.py:226). */
 int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t stream);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     text = open(os.path.join(ROOT, "include", "egom2p_hip.h")).read()
-    return set(re.findall(r"^\s*int\s+(ego_\w+)\s*\(", text, flags=re.M))
+    return set(re.findall(r"^\s*(?:int|long)\s+(ego_\w+)\s*\(", text, flags=re.M))
 
 
 def test_header_and_binding_agree():

@@ -64,6 +64,11 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
     eng.backward(1.0)
     torch.cuda.synchronize()
     plain = eng.G.clone()
+    eng.zero_grad()                                   # control: the plain path itself is bitwise reproducible
+    eng.forward(md, dec_order=order)
+    eng.backward(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.G, plain)
     own = not dist.is_initialized()
     if own:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -78,12 +83,10 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
             eng.backward(1.0, bucket_done=red.on_bucket)
             red.finish()
             torch.cuda.synchronize()
-            # weight gradients come out of deterministic split-K GEMMs: bitwise; the embedding / bias / LayerNorm-weight
-            # gradients are summed with float atomics (arrival order): equal to rounding
-            for n in ("encoder.0.attn.qkv.weight", "decoder.1.mlp.fc2.weight", "decoder.0.cross_attn.kv.weight", "decoder_proj_context.weight"):
-                lo, cnt, _ = eng.offsets[n]
-                assert torch.equal(eng.G[lo:lo + cnt], plain[lo:lo + cnt]), n
-            assert float((eng.G - plain).double().norm() / plain.double().norm()) < 1e-6
+            # every gradient kernel is free of float atomics (deterministic split-K GEMMs, dQ / dK / dV kernels without
+            # atomics, LayerNorm-weight / bias / embedding gradients through partial rows + ordered sums): the whole flat
+            # buffer is BITWISE that of the plain path - anything else is a stream / event ordering bug of the reducer
+            assert torch.equal(eng.G, plain), float((eng.G - plain).abs().max())
             spans = sorted(red.last_launched)
             assert spans[0][0] == 0 and spans[-1][1] == eng.n_flat
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])), spans
