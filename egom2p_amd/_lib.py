@@ -91,7 +91,7 @@ _SIGS = {
     "ego_cast_f32_bf16": [vp, vp, i64, vp],
     "ego_bias_grad_work_floats": [i64, i32],
     "ego_bias_grad": [vp, i64, i32, vp, vp, i64, vp],
-    "ego_grad_sqnorm": [vp, i64, vp, vp],
+    "ego_grad_sqnorm": [vp, i64, vp, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
     "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
 }

@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
                     mx = fmaxf(mx, v);
                 }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (fast) {
-            // scores are relative to m already; move the reference only where they outgrow it
+            // scores are relative to m already; move the reference only where they outgrow it.  The two half-waves hold
+            // the two key halves of a query's tile: they only have to agree on the maximum when the reference moves (rare)
             if (__any(mx > FWD_TAU)) {
+                mx = xhalf_max(mx);
                 const float d = fmaxf(mx, 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-d);
                 m += d;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
                 for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; st[0][i] -= d; st[1][i] -= d; }
             }
         } else {
+            mx = xhalf_max(mx);
             const float mnew = fmaxf(m, mx);
             if (__any(mnew > m)) {
                 const float alpha = __builtin_amdgcn_exp2f(m - mnew);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
         s_ = (s_ == 2) ? 0 : s_ + 1;
     }
 
-    const float lt = l + __shfl_xor(l, 32, 64);
+    const float lt = xhalf_sum(l);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     if (q0 + ql < p.Nq) {
         const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                 for (int e = 0; e < 8; ++e) delta += (float)ol[e] * (float)gf[s][e];
             }
         }
-        delta += __shfl_xor(delta, 32, 64);
+        delta = xhalf_sum(delta);
         if (hh == 0 && q0 + ql < p.Nq) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = -delta;
     }
     const float nlse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];       // -LSE2
@@ -735,18 +737,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // chains (8 MFMAs; the transposed reads land under them) | exp2 / multiply / pack | the NEXT block's 16 reads | dV^T /
     // dK^T chains (8 MFMAs; the next block's reads land under them).  NQB: the next block's index inside its tile; NRF /
     // NAUX: its fragment / constant addresses.
-#ifndef DKV_SCHED
-#define DKV_SCHED 1
-#endif
-    // One 32-row block, laid out in dependency order and pinned with sched_group_barrier pipelines (a wave issues in order:
-    // with all 8 S' / dP' MFMAs in front of the element-wise instructions - what hipcc emits for the plain source order - the
-    // wave's share of the MFMA pipe idles through its own exp2 / multiply / pack phase):
-    //   region 1:  S' chain (4 MFMAs) | dP' chain (4 MFMAs) with the 16 exp2 of S' in its gaps
-    //   region 2:  pack P | dV^T chain (4 MFMAs) with dS' = P o dP' and its packing in its gaps | dK^T chain (4 MFMAs)
-    // The mask classes only touch S' / dP' in two small side branches (before region 1: lanes outside a tile-wide interval
-    // start from -inf; between the regions: the per-element fix-up of the general class), so no branch carries the 64
-    // dK^T / dV^T accumulators (a class branch around the whole block made hipcc copy and spill them: 436 B of scratch).
-#define DKV_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define DKV_BLOCK(QB, NQB, NRF, NAUX)                                                                                    \
     {                                                                                                                    \
         dkv_wait(blk);                                                                                                   \
@@ -757,24 +747,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         if (cls == CLS_LANE) {           /* one interval for the whole tile: keys outside it start from -inf -> p = 0 */ \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) st[r] = lane_ok ? st[r] : -__builtin_inff();                  \
         }                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (DKV_SCHED == 0) {                                                                                            \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                             \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                             \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                  \
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                                 \
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                                 \
+        }                                                                                                                \
+        if (cls != CLS_GENERAL) {                                                                                        \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+                const float pe = __builtin_amdgcn_exp2f(st[r]);                                                          \
+                st[r] = pe;                                                                                              \
+                dp[r] = pe * dp[r];                                                                                      \
             }                                                                                                            \
-        } else {                                                                                                         \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0); \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0); \
-        }                                                                                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);                            \
-        if (DKV_SCHED == 1) {                                                                                            \
-            DKV_SGB(0x008, 4);                                                                                           \
-            DKV_SGB(0x008, 1); DKV_SGB(0x400, 3); DKV_SGB(0x008, 1); DKV_SGB(0x400, 3);                                  \
-            DKV_SGB(0x008, 1); DKV_SGB(0x400, 3); DKV_SGB(0x008, 1); DKV_SGB(0x400, 7);                                  \
-        }                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (cls == CLS_GENERAL) {     /* rows with different intervals, empty intervals, rows past Nq: per-element fix-up */ \
+        } else {              /* rows with different intervals, empty intervals, rows past Nq: per-element masks */      \
             const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);                                                \
             const int* ai = (const int*)(af + 128);                                                                      \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
@@ -785,46 +768,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     const bool flat = rke <= rks;                          /* empty interval: p = 1 / Nk, dS = 0 */      \
                     if (flat) { rks = 0; rke = p.Nk; }                                                                   \
                     const bool ok = (qt * 64 + qb0 + e < p.Nq) && (kidx >= rks) && (kidx < rke);                         \
-                    st[r] = ok ? (flat ? __builtin_amdgcn_exp2f(af[qb0 + e]) : st[r]) : 0.f;                             \
-                    dp[r] = flat ? 0.f : dp[r];                                                                          \
+                    const float pe = ok ? __builtin_amdgcn_exp2f(flat ? af[qb0 + e] : st[r]) : 0.f;                      \
+                    st[r] = pe;                                                                                          \
+                    dp[r] = flat ? 0.f : pe * dp[r];                                                                     \
                 }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1);                                                             \
-        if (DKV_SCHED != 0) __builtin_amdgcn_sched_barrier(0);                                                           \
+        const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1), ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                     \
         lgkm_wait_tied<0>(gfr);                                                                                          \
         lgkm_wait_tied<0>(qfr);                                                                                          \
         dkv_issue<NQB>(blk, NRF, NAUX);                                                                                  \
-        if (DKV_SCHED == 0) {                                                                                            \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) dp[r] = st[r] * dp[r];                                        \
-            const bf16x8 ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                                                         \
-            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                           \
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[db][0], gfr[db][1]), pf0, dvt[db], 0, 0, 0); \
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[db][0], qfr[db][1]), ds0, dkt[db], 0, 0, 0); \
-            }                                                                                                            \
-            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                           \
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 + db][0], gfr[2 + db][1]), pf1, dvt[db], 0, 0, 0); \
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 + db][0], qfr[2 + db][1]), ds1, dkt[db], 0, 0, 0); \
-            }                                                                                                            \
-        } else {                                                                                                         \
-            dvt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[0][0], gfr[0][1]), pf0, dvt[0], 0, 0, 0);         \
-            dvt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[1][0], gfr[1][1]), pf0, dvt[1], 0, 0, 0);         \
-            dvt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2][0], gfr[2][1]), pf1, dvt[0], 0, 0, 0);         \
-            dvt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[3][0], gfr[3][1]), pf1, dvt[1], 0, 0, 0);         \
-            /* each product is pinned as a scalar (empty asm): left alone, hipcc's SLP pass multiplies SHIFTED pairs with */ \
-            /* v_pk_mul_f32 and then spends 20 v_pk_mov / v_perm / v_alignbit instructions packing them to bf16 */        \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) { float t = st[r] * dp[r]; asm("" : "+v"(t)); dp[r] = t; }    \
-            const bf16x8 ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                                                         \
-            if (DKV_SCHED == 1) {                                                                                        \
-                DKV_SGB(0x008, 1); DKV_SGB(0x002, 6); DKV_SGB(0x008, 1); DKV_SGB(0x002, 6);                              \
-                DKV_SGB(0x008, 1); DKV_SGB(0x002, 6); DKV_SGB(0x008, 1); DKV_SGB(0x002, 6);                              \
-            }                                                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                                           \
-            dkt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[0][0], qfr[0][1]), ds0, dkt[0], 0, 0, 0);         \
-            dkt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[1][0], qfr[1][1]), ds0, dkt[1], 0, 0, 0);         \
-            dkt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2][0], qfr[2][1]), ds1, dkt[0], 0, 0, 0);         \
-            dkt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[3][0], qfr[3][1]), ds1, dkt[1], 0, 0, 0);         \
+        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[db][0], gfr[db][1]), pf0, dvt[db], 0, 0, 0);     \
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[db][0], qfr[db][1]), ds0, dkt[db], 0, 0, 0);     \
+        }                                                                                                                \
+        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 + db][0], gfr[2 + db][1]), pf1, dvt[db], 0, 0, 0); \
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 + db][0], qfr[2 + db][1]), ds1, dkt[db], 0, 0, 0); \
         }                                                                                                                \
     }
 
@@ -860,7 +820,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         for (int s = 0; s < 4; ++s) rfa[s] = rfn[s];
     }
 #undef DKV_BLOCK
-#undef DKV_SGB
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last (unused) prefetch
     for (int qt = wb; qt < nqt; ++qt) {                          // nothing left to compute
         ring_step(qt);

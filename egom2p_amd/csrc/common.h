@@ -43,25 +43,61 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// Wave-wide reductions on the VALU: four DPP steps (quad swaps, half-row mirror, row mirror) leave every lane of a 16-lane
+// row with the row's result, four v_readlane + scalar-operand ops join the rows.  (__shfl_xor compiles to ds_bpermute_b32:
+// six dependent LDS round trips per reduction, each behind an lgkmcnt(0) - on the critical path of every LayerNorm row and of
+// the attention kernels' prologues.)  The result is wave-uniform.
+#define EGO_DPP_QUAD_X1 0xB1       // quad_perm [1,0,3,2]
+#define EGO_DPP_QUAD_X2 0x4E       // quad_perm [2,3,0,1]
+#define EGO_DPP_HALF_MIRROR 0x141  // row_half_mirror
+#define EGO_DPP_MIRROR 0x140       // row_mirror
+#define EGO_DPP_F(v, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), ctrl, 0xF, 0xF, true))
+#define EGO_DPP_I(v, ctrl) (int)__builtin_amdgcn_update_dpp(0, (unsigned)(v), ctrl, 0xF, 0xF, true)
+#define EGO_RL_F(v, l) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += EGO_DPP_F(v, EGO_DPP_QUAD_X1);
+    v += EGO_DPP_F(v, EGO_DPP_QUAD_X2);
+    v += EGO_DPP_F(v, EGO_DPP_HALF_MIRROR);
+    v += EGO_DPP_F(v, EGO_DPP_MIRROR);
+    return (EGO_RL_F(v, 0) + EGO_RL_F(v, 16)) + (EGO_RL_F(v, 32) + EGO_RL_F(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, EGO_DPP_F(v, EGO_DPP_QUAD_X1));
+    v = fmaxf(v, EGO_DPP_F(v, EGO_DPP_QUAD_X2));
+    v = fmaxf(v, EGO_DPP_F(v, EGO_DPP_HALF_MIRROR));
+    v = fmaxf(v, EGO_DPP_F(v, EGO_DPP_MIRROR));
+    return fmaxf(fmaxf(EGO_RL_F(v, 0), EGO_RL_F(v, 16)), fmaxf(EGO_RL_F(v, 32), EGO_RL_F(v, 48)));
 }
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = min(v, EGO_DPP_I(v, EGO_DPP_QUAD_X1));
+    v = min(v, EGO_DPP_I(v, EGO_DPP_QUAD_X2));
+    v = min(v, EGO_DPP_I(v, EGO_DPP_HALF_MIRROR));
+    v = min(v, EGO_DPP_I(v, EGO_DPP_MIRROR));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, EGO_DPP_I(v, EGO_DPP_QUAD_X1));
+    v = max(v, EGO_DPP_I(v, EGO_DPP_QUAD_X2));
+    v = max(v, EGO_DPP_I(v, EGO_DPP_HALF_MIRROR));
+    v = max(v, EGO_DPP_I(v, EGO_DPP_MIRROR));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// max of a value with the one held by lane ^ 32 (the other half-wave), on the VALU: v_permlane32_swap exchanges the upper
+// half of its first operand with the lower half of its second, so {r0, r1} = {own, other} in lanes 0-31 and {other, own} in
+// lanes 32-63.  (__shfl_xor(x, 32) compiles to ds_bpermute_b32: an LDS round trip plus an lgkmcnt(0) that also waits for
+// every LDS read the wave has in flight.)
+__device__ __forceinline__ float xhalf_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // LDS transposed read: per 16-lane group a 4(row) x 16(col) block of 16-bit elements; lane i of

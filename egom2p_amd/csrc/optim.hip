@@ -10,7 +10,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n4, long n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n4, long n, double* __restrict__ out,
+                                                     double* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -22,7 +23,18 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (double)(red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) {
+        const double t = (double)(red[0] + red[1] + red[2] + red[3]);
+        if (part) part[blockIdx.x] = t;        // summed in block order by sqnorm_finish_kernel: bitwise reproducible
+        else atomicAdd(out, t);
+    }
+}
+
+__global__ __launch_bounds__(64) void sqnorm_finish_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += part[i];
+    *out += s;
 }
 
 // p, g, m, v: flat fp32 of length n.  sqnorm: device double, sum of squares of the RAW grads.
@@ -67,13 +79,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 
 extern "C" int ego_abi_version(void) { return EGO_ABI_VERSION; }
 
-extern "C" int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t stream) {
+extern "C" int ego_grad_sqnorm(const float* g, long n, double* out, double* work, hipStream_t stream) {
     if (n <= 0) return EGO_OK;
     if (((uintptr_t)g) % 16) return EGO_ERR_ARG;
     const long n4 = n / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    EGO_LAUNCH(sqnorm_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, g, n4, n, out);
+    int blocks = (int)((n4 + 255) / 256 < EGO_SQNORM_WORK ? (n4 + 255) / 256 : EGO_SQNORM_WORK);
+    if (blocks < 1) blocks = 1;
+    EGO_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, g, n4, n, out, work);
     LAUNCH_CHECK();
+    if (work) {
+        EGO_LAUNCH(sqnorm_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)work, blocks, out);
+        LAUNCH_CHECK();
+    }
     return EGO_OK;
 }
 

@@ -24,11 +24,21 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0, force: bool = False,
-                 skip: Sequence[str] = ()):
+                 skip: Sequence[str] = (), algo: Optional[str] = None):
+        """algo: "allreduce" (RCCL's all-reduce: a ring, bound by one xGMI link per hop - fine while a step has ~1 s of
+        backward to hide it) or "rs_ag": reduce-scatter + all-gather of the same bucket, in place - every rank sums one
+        1/world shard and the shards travel over all 7 links at once (~2.6 ms against ~18 ms ring for
+        the 1.585 GB of gradients; what a step at the released yaml's 4 clips per GPU needs).  Default: $EGOM2P_DP_ALGO or
+        "allreduce".  Same sums either way up to the order of the floating-point additions across ranks."""
+        import os
+        self.algo = algo or os.environ.get("EGOM2P_DP_ALGO", "allreduce")
+        if self.algo not in ("allreduce", "rs_ag"):
+            raise ValueError(f"GradBucketReducer: unknown algo {self.algo!r}")
         self.G = flat_grad
         self.skip = set(skip)                   # bucket names exchanged by other means (SparseTableExchange)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: rehearse the path with one rank
         self.cap = int(bucket_cap_mb * 1024 * 1024 / flat_grad.element_size())
         self.cuda = flat_grad.is_cuda
@@ -53,17 +63,34 @@ class GradBucketReducer:
             self._launch(*self._pending)
             self._pending = None
 
-    def _launch(self, lo: int, hi: int):
+    def _exchange(self, lo: int, hi: int):
+        """the collective(s) of one bucket, issued on the current stream (the comm stream on the GPU)"""
         view = self.G[lo:hi]
+        cnt = (hi - lo) // self.world
+        if self.algo == "rs_ag" and cnt > 0:
+            main = view[:cnt * self.world]
+            shard = main[self.rank * cnt:(self.rank + 1) * cnt]            # in place: this rank's shard of the bucket
+            w = dist.reduce_scatter_tensor(shard, main, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if not self.cuda:
+                w.wait()                                                   # gloo: no stream order between two collectives
+            else:
+                self._works.append(w)
+            self._works.append(dist.all_gather_into_tensor(main, shard, group=self.pg, async_op=True))
+            if cnt * self.world < hi - lo:                                 # fewer than `world` elements left over
+                self._works.append(dist.all_reduce(view[cnt * self.world:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _launch(self, lo: int, hi: int):
         self.launched.append((lo, hi))
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._exchange(lo, hi)
         else:
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._exchange(lo, hi)
 
     def finish(self):
         """Flush the tail bucket and make the compute stream wait for every outstanding all-reduce
@@ -153,14 +180,14 @@ class SparseTableExchange:
 class DataParallel(torch.nn.Module):
     """DDP-shaped wrapper for `egom2p_amd.model.EgoM2P` (`.module`, `no_sync()`, forward passthrough)."""
 
-    def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb: float = 32.0, **_):
+    def __init__(self, module, device_ids=None, process_group=None, bucket_cap_mb: float = 32.0, algo: Optional[str] = None, **_):
         super().__init__()
         self.module = module
         eng = module.engine
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
             dist.broadcast(eng.P, src=0, group=process_group)      # DDP ctor broadcast (run_training_egom2p.py:514)
             eng.weights_dirty = True
-        self.reducer = GradBucketReducer(eng.G, process_group, bucket_cap_mb)
+        self.reducer = GradBucketReducer(eng.G, process_group, bucket_cap_mb, algo=algo)
         module._bucket_done = self.reducer.on_bucket
         module._after_backward = self.reducer.finish
 

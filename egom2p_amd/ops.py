@@ -220,8 +220,14 @@ def bias_grad(g, rows, D, db):
     check(lib.ego_bias_grad(_p(g), rows, D, _p(db), _p(wk), wk.numel(), _stream()), "ego_bias_grad")
 
 
+_SQ_WORK = {}
+
+
 def grad_sqnorm(g, out):
-    check(L.load().ego_grad_sqnorm(_p(g), g.numel(), _p(out), _stream()), "ego_grad_sqnorm")
+    wk = _SQ_WORK.get(g.device)
+    if wk is None:
+        wk = _SQ_WORK[g.device] = torch.empty(2048, device=g.device, dtype=torch.float64)      # EGO_SQNORM_WORK
+    check(L.load().ego_grad_sqnorm(_p(g), g.numel(), _p(out), _p(wk), _stream()), "ego_grad_sqnorm")
 
 
 def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.95, eps=1e-8, gscale=1.0, max_norm=0.0, sqnorm=None,

@@ -19,7 +19,7 @@ from .optim import FusedAdamW
 class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4, weight_decay: float = 0.05, clip_grad: Optional[float] = 1.0,
                  process_group=None, world_size: int = 1, seed: int = 0, force_reducer: bool = False,
-                 clips_per_step: Optional[int] = None, sparse_tables: str = "auto"):
+                 clips_per_step: Optional[int] = None, sparse_tables: str = "auto", dp_algo: Optional[str] = None):
         """clips_per_step (per rank) bounds the table rows one step can touch (clips x kept encoder tokens); with
         sparse_tables = "auto" the encoder tables' gradients go through the row-list exchange when that moves fewer bytes
         than the dense all-reduce ("on" / "off" force it)."""
@@ -42,7 +42,7 @@ class TrainStep:
                 if picked:
                     self.sparse = SparseTableExchange([(g, fl) for g, fl, _ in picked], cap, process_group)
                     skip = tuple(f"enc_table.{m.name}" for _, _, m in picked)
-        self.reducer = (GradBucketReducer(engine.G, process_group, force=force_reducer, skip=skip)
+        self.reducer = (GradBucketReducer(engine.G, process_group, force=force_reducer, skip=skip, algo=dp_algo)
                         if (world_size > 1 or force_reducer) else None)
         self.rng = random.Random(seed)           # decoder modality shuffle (egom2p_model.py:312), per forward
         self.loss_sum = torch.zeros(1 + engine.n_mods, device=engine.dev)

@@ -254,7 +254,10 @@ long ego_bias_grad_work_floats(long rows, int D);
 int ego_bias_grad(const void* g_bf16, long rows, int D, float* db, float* work, long work_floats, hipStream_t stream);
 
 /* clip_grad_norm_ + AdamW over flat buffers (egom2p/utils/native_scaler.py:28-43, optim_factory.py:226). */
-int ego_grad_sqnorm(const float* g, long n, double* out, hipStream_t stream);
+/* *out += sum g^2.  work: EGO_SQNORM_WORK doubles of scratch - per-workgroup partial sums added in workgroup order (bitwise
+ * reproducible); NULL: one double atomic per workgroup. */
+#define EGO_SQNORM_WORK 2048
+int ego_grad_sqnorm(const float* g, long n, double* out, double* work, hipStream_t stream);
 int ego_adamw_step(float* p, float* g, float* m, float* v, long n, float lr, float wd, float beta1, float beta2, float eps,
                    int step, float gscale, float max_norm, const double* sqnorm, int zero_grad, hipStream_t stream);
 

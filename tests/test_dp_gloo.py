@@ -39,7 +39,7 @@ def _flat_grads(cfg, sd, md, order):
     return torch.cat(parts), names
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, algo="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -49,7 +49,7 @@ def _worker(rank, world, port, ret):
     order = ["tok_gaze", "tok_cam"]
     mine = {k: {kk: vv[2 * rank:2 * rank + 2] for kk, vv in v.items()} for k, v in md.items()}
     G, names = _flat_grads(cfg, sd, mine, order)
-    red = GradBucketReducer(G, bucket_cap_mb=0.25)
+    red = GradBucketReducer(G, bucket_cap_mb=0.25, algo=algo)
     # report buckets tail-first, tensor by tensor, as the hand-ordered backward does
     hi = G.numel()
     for name, n in reversed(names):
@@ -70,11 +70,14 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_matches_full_batch():
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bucketed_allreduce_matches_full_batch(algo):
+    """both exchange algorithms of GradBucketReducer: RCCL-style all-reduce per bucket, and reduce-scatter + all-gather in
+    place (bucket sizes are not multiples of the world size here: the leftover elements take the all-reduce path)"""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, algo), nprocs=2, join=True)
     assert ret["err"] < 1e-5, dict(ret)
 
 

@@ -52,7 +52,8 @@ def test_non_interval_decoder_mask_poisons_the_loss():
     assert int(eng.cd["err"].item()) == 0
 
 
-def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent(algo):
     """the event on the compute stream, the all_reduce on the comm stream and finish() had never run on a GPU.
     World size 1 makes the all-reduce the identity, so gradients must be bitwise those of the plain path, and the buckets
     must tile [0, n_flat) exactly once."""
@@ -75,7 +76,7 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent():
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        red = GradBucketReducer(eng.G, None, bucket_cap_mb=0.25, force=True)
+        red = GradBucketReducer(eng.G, None, bucket_cap_mb=0.25, force=True, algo=algo)
         assert red.active
         for rep in range(2):
             eng.zero_grad()
