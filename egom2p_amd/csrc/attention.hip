@@ -204,13 +204,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
     float sc = p.scale * LOG2E;
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
-    const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
-    const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
-    int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
-    if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
-    __syncthreads();
-    const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
-    const int kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    // one interval per sample (encoder self-attention, cross-attention): every row of the workgroup has the same [ks, ke) -
+    // no reductions (24 dependent ds_bpermute round trips per wave otherwise, ~8 % of a workgroup's life)
+    int w_lo = ks, w_hi = ke, w_ksmax = ks, w_kemin = ke, kmin = ks, kmax = ke;
+    if (p.r_rs != 0) {
+        w_lo = wave_min_i(ks); w_hi = wave_max_i(ke);
+        w_ksmax = wave_max_i(ks); w_kemin = wave_min_i(ke);
+        int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
+        if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
+        __syncthreads();
+        kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
+        kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    }
+    // (readfirstlane: these feed the scalar offsets of the LDS-DMA - as VGPR values hipcc wraps every DMA in a waterfall loop)
+    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
     const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
@@ -387,13 +394,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
     float sc = p.scale * LOG2E, gsc = p.scale;
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }       // empty interval: q' = 0 -> p = exp2(-LSE2) = 1 / Nk, dQ = 0
-    const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
-    const int w_ksmax = wave_max_i(ks), w_kemin = wave_min_i(ke);
-    int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
-    if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
-    __syncthreads();
-    const int kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
-    const int kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    // one interval per sample (encoder self-attention, cross-attention): every row of the workgroup has the same [ks, ke) -
+    // no reductions (24 dependent ds_bpermute round trips per wave otherwise, ~8 % of a workgroup's life)
+    int w_lo = ks, w_hi = ke, w_ksmax = ks, w_kemin = ke, kmin = ks, kmax = ke;
+    if (p.r_rs != 0) {
+        w_lo = wave_min_i(ks); w_hi = wave_max_i(ke);
+        w_ksmax = wave_max_i(ks); w_kemin = wave_min_i(ke);
+        int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
+        if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
+        __syncthreads();
+        kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
+        kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    }
+    // (readfirstlane: these feed the scalar offsets of the LDS-DMA - as VGPR values hipcc wraps every DMA in a waterfall loop)
+    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
     const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;

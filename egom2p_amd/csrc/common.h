@@ -52,7 +52,6 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 #define EGO_DPP_HALF_MIRROR 0x141  // row_half_mirror
 #define EGO_DPP_MIRROR 0x140       // row_mirror
 #define EGO_DPP_F(v, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), ctrl, 0xF, 0xF, true))
-#define EGO_DPP_I(v, ctrl) (int)__builtin_amdgcn_update_dpp(0, (unsigned)(v), ctrl, 0xF, 0xF, true)
 #define EGO_RL_F(v, l) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l))
 __device__ __forceinline__ float wave_sum(float v) {
     v += EGO_DPP_F(v, EGO_DPP_QUAD_X1);
@@ -68,21 +67,17 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, EGO_DPP_F(v, EGO_DPP_MIRROR));
     return fmaxf(fmaxf(EGO_RL_F(v, 0), EGO_RL_F(v, 16)), fmaxf(EGO_RL_F(v, 32), EGO_RL_F(v, 48)));
 }
+// (the integer reductions stay on __shfl_xor: they only run in kernel prologues, and with wave-uniform DPP / readlane results
+// hipcc's register allocation of the attention forward kernel went from 144 VGPRs to 168 + 96 B of scratch)
 __device__ __forceinline__ int wave_min_i(int v) {
-    v = min(v, EGO_DPP_I(v, EGO_DPP_QUAD_X1));
-    v = min(v, EGO_DPP_I(v, EGO_DPP_QUAD_X2));
-    v = min(v, EGO_DPP_I(v, EGO_DPP_HALF_MIRROR));
-    v = min(v, EGO_DPP_I(v, EGO_DPP_MIRROR));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-    v = max(v, EGO_DPP_I(v, EGO_DPP_QUAD_X1));
-    v = max(v, EGO_DPP_I(v, EGO_DPP_QUAD_X2));
-    v = max(v, EGO_DPP_I(v, EGO_DPP_HALF_MIRROR));
-    v = max(v, EGO_DPP_I(v, EGO_DPP_MIRROR));
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // max of a value with the one held by lane ^ 32 (the other half-wave), on the VALU: v_permlane32_swap exchanges the upper

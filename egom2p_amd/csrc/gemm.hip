@@ -258,6 +258,13 @@ __device__ __forceinline__ void bar_pinned() {
 // The bf16 epilogue runs in two 128-row passes through the A and B stages the last K-step left free, and its stores
 // drain under the next tile.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant, tile and K
 // position are the scalar offset, rows past M / N read as zeros.  K >= 128.
+// cache policy of the operand DMAs (aux of buffer_load ... lds: 0 default, 2 = nt: streamed, evict-first in L2)
+#ifndef NT256_A_AUX
+#define NT256_A_AUX 0
+#endif
+#ifndef NT256_B_AUX
+#define NT256_B_AUX 0
+#endif
 constexpr int RA_BYTES = 256 * 128;                // one ring slot of either operand: 256 rows x 64 bf16 = 32 KiB
 constexpr int NT3_LDS = 5 * RA_BYTES;              // A slots 0..2, B slots 3..4
 
@@ -338,11 +345,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     };
     auto dmaA = [&](int slot, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + slot * RA_BYTES + (wave * 4 + j) * 1024),
-                                                 16, a_off0, (int)(a_so + j * a_step), 0, 0);
+                                                 16, a_off0, (int)(a_so + j * a_step), 0, NT256_A_AUX);
     };
     auto dmaB = [&](int slot, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + (3 + slot) * RA_BYTES + (wave * 4 + j) * 1024),
-                                                 16, b_off0, (int)(b_so + j * b_step), 0, 0);
+                                                 16, b_off0, (int)(b_so + j * b_step), 0, NT256_B_AUX);
     };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
