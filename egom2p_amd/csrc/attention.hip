@@ -751,20 +751,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // chains (8 MFMAs; the transposed reads land under them) | exp2 / multiply / pack | the NEXT block's 16 reads | dV^T /
     // dK^T chains (8 MFMAs; the next block's reads land under them).  NQB: the next block's index inside its tile; NRF /
     // NAUX: its fragment / constant addresses.
+#ifndef ATT_ABL
+#define ATT_ABL 0      // timing-only ablation builds (WRONG results): 1 = no exp2 / multiply / pack, 2 = LDS reads only in a wave's first tile, 4 = no MFMAs
+#endif
+    s16x4 gfr[4][2], qfr[4][2];
 #define DKV_BLOCK(QB, NQB, NRF, NAUX)                                                                                    \
     {                                                                                                                    \
         dkv_wait(blk);                                                                                                   \
-        s16x4 gfr[4][2], qfr[4][2];                                                                                      \
-        tr_issue<TILE_BYTES, 2 * QB>(tra, s_ * 2 * TILE_BYTES, gfr);                                                     \
-        tr_issue<0, 2 * QB>(tra, s_ * 2 * TILE_BYTES, qfr);                                                              \
+        if (!(ATT_ABL & 2) || qt == wa) {                                                                                \
+            tr_issue<TILE_BYTES, 2 * QB>(tra, s_ * 2 * TILE_BYTES, gfr);                                                 \
+            tr_issue<0, 2 * QB>(tra, s_ * 2 * TILE_BYTES, qfr);                                                          \
+        }                                                                                                                \
         f32x16 st = cat16(blk.cs), dp = cat16(blk.cd);                                                                   \
         if (cls == CLS_LANE) {           /* one interval for the whole tile: keys outside it start from -inf -> p = 0 */ \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) st[r] = lane_ok ? st[r] : -__builtin_inff();                  \
         }                                                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                  \
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                                 \
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                                 \
+        if (!(ATT_ABL & 4)) {                                                                                            \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                             \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                             \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(blk.rq[s]), "v"(blk.rg[s]));            \
         }                                                                                                                \
+        bf16x8 pf0, pf1, ds0, ds1;                                                                                       \
+        if (ATT_ABL & 1) {                                                                                               \
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));                                                    \
+            pf0 = __builtin_bit_cast(bf16x8, f32x4_{st[0], st[1], st[2], st[3]});                                        \
+            pf1 = __builtin_bit_cast(bf16x8, f32x4_{st[4], st[5], st[6], st[7]});                                        \
+            ds0 = __builtin_bit_cast(bf16x8, f32x4_{dp[0], dp[1], dp[2], dp[3]});                                        \
+            ds1 = __builtin_bit_cast(bf16x8, f32x4_{dp[4], dp[5], dp[6], dp[7]});                                        \
+            asm volatile("" :: "v"(st), "v"(dp));                                                                        \
+        } else {                                                                                                         \
         if (cls != CLS_GENERAL) {                                                                                        \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
                 const float pe = __builtin_amdgcn_exp2f(st[r]);                                                          \
@@ -788,10 +806,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                 }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
-        const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1), ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                     \
+        pf0 = pack8(st, 0); pf1 = pack8(st, 1); ds0 = pack8(dp, 0); ds1 = pack8(dp, 1);                                  \
+        }                                                                                                                \
         lgkm_wait_tied<0>(gfr);                                                                                          \
         lgkm_wait_tied<0>(qfr);                                                                                          \
-        dkv_issue<NQB>(blk, NRF, NAUX);                                                                                  \
+        if (!(ATT_ABL & 2) || qt == wa) dkv_issue<NQB>(blk, NRF, NAUX);                                                  \
+        if (!(ATT_ABL & 4)) {                                                                                            \
         _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
             dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[db][0], gfr[db][1]), pf0, dvt[db], 0, 0, 0);     \
             dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[db][0], qfr[db][1]), ds0, dkt[db], 0, 0, 0);     \
@@ -799,6 +819,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
             dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 + db][0], gfr[2 + db][1]), pf1, dvt[db], 0, 0, 0); \
             dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 + db][0], qfr[2 + db][1]), ds1, dkt[db], 0, 0, 0); \
+        }                                                                                                                \
+        } else {                                                                                                         \
+            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(ds0), "v"(ds1));                                                  \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4)                                                             \
+                asm volatile("" :: "v"(gfr[q4][0]), "v"(gfr[q4][1]), "v"(qfr[q4][0]), "v"(qfr[q4][1]));                  \
         }                                                                                                                \
     }
 
