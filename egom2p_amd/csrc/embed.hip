@@ -465,19 +465,48 @@ __global__ __launch_bounds__(256) void embed_tables_kernel(EmbedBwdArgs a) {
         n = 0;
     };
 
+    // this lane's key for row r, or -1 (not a table row of this workgroup)
+    auto key_of = [&](long r) -> int {
+        if (r >= a.rows) return -1;
+        const int sl = a.slot[r];
+        if (sl < 0) return -1;
+        bool has = false;
+#pragma unroll
+        for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == sl) has = a.dtable[m] != nullptr;
+        const int t = a.tok[r];
+        return (has && (t & (ET_WGS - 1)) == j) ? ((sl << 16) | t) : -1;
+    };
+    // Fast path (the usual case: a workgroup owns ~rows / ET_WGS pairs): wave w scans the w-th quarter of the rows on its own
+    // - no workgroup barrier per step - first counting its pairs, then, with the four counts known, writing them at its
+    // offset: the list is in row order.  Falls back to the stepwise scan with flushes when the pairs do not fit.
+    const long quarter = ((a.rows + 3) / 4 + 63) / 64 * 64;
+    const long q0 = wave * quarter, q1 = min(a.rows, q0 + quarter);
+    int mine = 0;
+    for (long base = q0; base < q1; base += 64) mine += __builtin_popcountll(__ballot(key_of(base + lane) >= 0));
+    if (lane == 0) wcnt[wave] = mine;
+    __syncthreads();
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (total <= ET_CAP) {
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        __syncthreads();
+        for (long base = q0; base < q1; base += 64) {
+            const int key = key_of(base + lane);
+            const unsigned long long m = __ballot(key >= 0);
+            if (key >= 0) {
+                const int pos = off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                lkey[pos] = key; lrow[pos] = (int)(base + lane);
+            }
+            off += __builtin_popcountll(m);
+        }
+        n = total;
+        if (n > 0) flush();
+        return;
+    }
+    __syncthreads();
     for (long base = 0; base < a.rows; base += 256) {
         const long r = base + tid;
-        int key = -1;
-        if (r < a.rows) {
-            const int s = a.slot[r];
-            if (s >= 0) {
-                bool has = false;
-#pragma unroll
-                for (int m = 0; m < EGO_MAX_MODS; ++m) if (m == s) has = a.dtable[m] != nullptr;
-                const int t = a.tok[r];
-                if (has && (t & (ET_WGS - 1)) == j) key = (s << 16) | t;
-            }
-        }
+        const int key = key_of(r);
         const unsigned long long m = __ballot(key >= 0);
         if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
         __syncthreads();
