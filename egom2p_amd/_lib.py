@@ -94,6 +94,11 @@ _SIGS = {
     "ego_grad_sqnorm": [vp, i64, vp, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
     "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
+    "ego_dp_unique_id": [vp],
+    "ego_dp_comm_create": [vp, i32, i32, C.POINTER(vp)],
+    "ego_dp_comm_destroy": [vp],
+    "ego_dp_allreduce_begin": [vp, vp, i64, i32, vp, vp],
+    "ego_dp_wait": [vp, vp, vp],
 }
 
 EXPORTS = tuple(_SIGS)

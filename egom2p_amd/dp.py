@@ -22,9 +22,47 @@ import torch
 import torch.distributed as dist
 
 
+class CabiComm:
+    """The C-ABI's own RCCL communicator (`ego_dp_*`, include/egom2p_hip.h): what a host without torch.distributed would use
+    for the gradient exchange.  torch.distributed is only the bootstrap channel here - rank 0's 128-byte unique id travels to
+    the other ranks through the existing process group's store (any backend); the exchange itself is RCCL called from the
+    library on the streams given."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes as C
+        from . import _lib as L
+        self.lib = L.load()
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        torch.cuda.set_device(device)
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(self.lib.ego_dp_unique_id(buf), "ego_dp_unique_id")
+        box = [bytes(buf.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=process_group)
+        self.handle = C.c_void_p()
+        L.check(self.lib.ego_dp_comm_create(C.c_char_p(box[0]), self.rank, self.world, C.byref(self.handle)), "ego_dp_comm_create")
+
+    def allreduce_begin(self, view: torch.Tensor, algo: str, compute_stream, comm_stream):
+        from . import _lib as L
+        assert view.is_cuda and view.dtype == torch.float32 and view.is_contiguous()
+        L.check(self.lib.ego_dp_allreduce_begin(self.handle, view.data_ptr(), view.numel(), 1 if algo == "rs_ag" else 0,
+                                                compute_stream.cuda_stream, comm_stream.cuda_stream), "ego_dp_allreduce_begin")
+
+    def wait(self, compute_stream, comm_stream):
+        from . import _lib as L
+        L.check(self.lib.ego_dp_wait(self.handle, compute_stream.cuda_stream, comm_stream.cuda_stream), "ego_dp_wait")
+
+    def close(self):
+        if self.handle:
+            self.lib.ego_dp_comm_destroy(self.handle)
+            self.handle = None
+
+
 class GradBucketReducer:
     def __init__(self, flat_grad: torch.Tensor, process_group=None, bucket_cap_mb: float = 32.0, force: bool = False,
-                 skip: Sequence[str] = (), algo: Optional[str] = None):
+                 skip: Sequence[str] = (), algo: Optional[str] = None, cabi_comm: Optional[CabiComm] = None):
         """algo: "allreduce" (RCCL's all-reduce: a ring, bound by one xGMI link per hop - fine while a step has ~1 s of
         backward to hide it) or "rs_ag": reduce-scatter + all-gather of the same bucket, in place - every rank sums one
         1/world shard and the shards travel over all 7 links at once (~2.6 ms against ~18 ms ring for
@@ -43,6 +81,7 @@ class GradBucketReducer:
         self.cap = int(bucket_cap_mb * 1024 * 1024 / flat_grad.element_size())
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.cabi = cabi_comm                    # exchange through the library's own RCCL communicator instead of torch.distributed
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []     # for tests / introspection
@@ -83,7 +122,9 @@ class GradBucketReducer:
 
     def _launch(self, lo: int, hi: int):
         self.launched.append((lo, hi))
-        if self.cuda:
+        if self.cuda and self.cabi is not None:
+            self.cabi.allreduce_begin(self.G[lo:hi], self.algo, torch.cuda.current_stream(), self.comm_stream)
+        elif self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -102,7 +143,9 @@ class GradBucketReducer:
             self._pending = None
         for w in self._works:
             w.wait()
-        if self.cuda:
+        if self.cuda and self.cabi is not None:
+            self.cabi.wait(torch.cuda.current_stream(), self.comm_stream)
+        elif self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works.clear()
         self.last_launched, self.launched = self.launched, []

@@ -261,6 +261,23 @@ int ego_grad_sqnorm(const float* g, long n, double* out, double* work, hipStream
 int ego_adamw_step(float* p, float* g, float* m, float* v, long n, float lr, float wd, float beta1, float beta2, float eps,
                    int step, float gscale, float max_norm, const double* sqnorm, int zero_grad, hipStream_t stream);
 
+/* ---- data-parallel gradient exchange (RCCL over xGMI) ---------------------------------------- */
+
+/* Replaces DistributedDataParallel's gradient all-reduce for the reference (run_training_egom2p.py:514-515, :723;
+ * egom2p/utils/dist.py:78-100): one process per GPU, one communicator per process.  Rank 0 calls ego_dp_unique_id and hands
+ * the 128 bytes to the other ranks by whatever launcher channel exists (egom2p_amd/dp.py broadcasts them through
+ * torch.distributed's store); every rank then calls ego_dp_comm_create (collective).  ego_dp_allreduce_begin sums
+ * buf[0, count) over the ranks IN PLACE on comm_stream, ordered behind what compute_stream holds at the time of the call, and
+ * returns at once (algo 0: all-reduce, 1: reduce-scatter + all-gather in place); ego_dp_wait makes compute_stream wait for
+ * the exchanges issued so far.  RCCL is resolved with dlopen at first use (no link-time dependency). */
+typedef struct ego_dp_comm ego_dp_comm;
+int ego_dp_unique_id(void* out128);
+int ego_dp_comm_create(const void* unique_id128, int rank, int world, ego_dp_comm** out);
+int ego_dp_comm_destroy(ego_dp_comm* comm);
+int ego_dp_allreduce_begin(ego_dp_comm* comm, float* buf, long count, int algo, hipStream_t compute_stream,
+                           hipStream_t comm_stream);
+int ego_dp_wait(ego_dp_comm* comm, hipStream_t compute_stream, hipStream_t comm_stream);
+
 #ifdef __cplusplus
 }
 #endif

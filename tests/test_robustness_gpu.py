@@ -52,7 +52,7 @@ def test_non_interval_decoder_mask_poisons_the_loss():
     assert int(eng.cd["err"].item()) == 0
 
 
-@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag", "cabi:allreduce", "cabi:rs_ag"])
 def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent(algo):
     """the event on the compute stream, the all_reduce on the comm stream and finish() had never run on a GPU.
     World size 1 makes the all-reduce the identity, so gradients must be bitwise those of the plain path, and the buckets
@@ -71,12 +71,16 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent(algo):
     torch.cuda.synchronize()
     assert torch.equal(eng.G, plain)
     own = not dist.is_initialized()
+    cabi = None
     if own:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        red = GradBucketReducer(eng.G, None, bucket_cap_mb=0.25, force=True, algo=algo)
+        if algo.startswith("cabi:"):                  # the library's own RCCL communicator (ego_dp_*, include/egom2p_hip.h)
+            from egom2p_amd.dp import CabiComm
+            cabi, algo = CabiComm(eng.dev), algo[5:]
+        red = GradBucketReducer(eng.G, None, bucket_cap_mb=0.25, force=True, algo=algo, cabi_comm=cabi)
         assert red.active
         for rep in range(2):
             eng.zero_grad()
@@ -93,6 +97,8 @@ def test_bucket_reducer_on_a_one_rank_rccl_group_is_bit_transparent(algo):
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])), spans
             assert len(spans) > 1
     finally:
+        if cabi is not None:
+            cabi.close()
         if own:
             dist.destroy_process_group()
 
