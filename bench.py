@@ -249,7 +249,7 @@ def main():
         # live HIP-event timing of one micro-batch forward+backward, per kernel class
         kt = KernelTimer()
         with kt.capture(cfg.num_heads):
-            eng.forward(mbs[0], dec_order=[m.name for m in cfg.mods])
+            eng.forward(mbs[0], dec_order=[m.name for m in cfg.mods], loss_grad=1.0)
             eng.backward(1.0)
         eng.zero_grad()
         summ = kt.summary()

@@ -86,6 +86,7 @@ _SIGS = {
     "ego_gemm_nt_swiglu_fwd": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "ego_ce_fwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp],
     "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp],
+    "ego_ce_fwd_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp, i32, vp],
     "ego_loss_finalize": [vp, vp, i32, vp, vp, vp],
     "ego_cast_weight": [vp, i32, i32, i64, vp, i64, vp, i64, i32, vp],
     "ego_cast_f32_bf16": [vp, vp, i64, vp],

@@ -344,6 +344,81 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits
     }
 }
 
+// Forward and backward of the cross-entropy in ONE pass over the logits (training: the upstream gradient is known when
+// the loss is formed).  The row lives in registers between the two phases (NCH 16-byte chunks per thread: 128 KB at
+// V = 64000 is 32 chunks for each of 256 threads), so the logits are read once instead of twice.  Same fold order, same
+// expressions as ce_fwd_kernel / ce_bwd_kernel: lse, nll and d logits are bitwise those of the two-call form.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V,
+                                                         const int* __restrict__ targets, const int* __restrict__ range,
+                                                         float* __restrict__ lse_out, float* __restrict__ nll_out,
+                                                         const float* __restrict__ gscale, float inv_mods) {
+    __shared__ float red[9];
+    const int off = range[0], n = range[1];
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const long row = (long)off + r;
+    bf16_t* lr = logits + row * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vc = V >> 3;
+    const int tgt = targets[row];
+    u32x4 a[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < vc) a[j] = *(const u32x4*)(lr + c * 8);
+    }
+    float mx = -3.0e38f, s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (threadIdx.x + 256 * j < vc) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[2 * e] = bf16_to_f32(a[j][e] & 0xffff); x[2 * e + 1] = bf16_to_f32(a[j][e] >> 16); }
+            float cm = x[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) cm = fmaxf(cm, x[e]);
+            if (cm > mx) { s *= __expf(mx - cm); mx = cm; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += __expf(x[e] - mx);
+        }
+    }
+    const float wm = wave_max(mx);
+    s = wave_sum(s * __expf(mx - wm));
+    if (lane == 0) { red[wave] = wm; red[4 + wave] = s; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        const float tot = red[4] * __expf(red[0] - mx) + red[5] * __expf(red[1] - mx) + red[6] * __expf(red[2] - mx) + red[7] * __expf(red[3] - mx);
+        const float l = mx + __logf(tot);
+        red[8] = l;
+        lse_out[row] = l;
+        nll_out[row] = l - bf16_to_f32(lr[tgt]);
+    }
+    __syncthreads();                         // (also orders thread 0's read of the target logit before the stores below)
+    const float lse = red[8];
+    const float coef = gscale[0] * inv_mods / (float)n;
+    // (the row stays PACKED across the barrier: without this hipcc keeps the first phase's 8 floats per chunk alive too)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(a[j]));
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < vc) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i0 = c * 8 + 2 * e;
+                float p0 = __expf(bf16_to_f32(a[j][e] & 0xffff) - lse), p1 = __expf(bf16_to_f32(a[j][e] >> 16) - lse);
+                if (i0 == tgt) p0 -= 1.f;
+                if (i0 + 1 == tgt) p1 -= 1.f;
+                o[e] = pack_bf16x2(p0 * coef, p1 * coef);
+            }
+            *(u32x4*)(lr + c * 8) = o;
+        }
+    }
+}
+
 // mod_loss[m] = sum(nll[off..off+n)) / n (0 if n == 0); loss = sum_m mod_loss / n_mods.  One block.
 // One workgroup of 1024 threads, 4 independent 16-byte loads in flight per thread: the 65,536 per-row losses of a
 // micro-batch (256 KB) are four round trips, and the sum order is fixed (bitwise reproducible).  `err` (optional): the
@@ -566,6 +641,19 @@ extern "C" int ego_ce_bwd(void* logits, long ld, int V, const int* targets, cons
     if (max_rows <= 0) return EGO_OK;
     if (V % 8 || ld % 8 || n_mods <= 0) return EGO_ERR_ARG;
     EGO_LAUNCH(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_ce_fwd_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse,
+                              float* nll, const float* gscale, int n_mods, hipStream_t stream) {
+    if (max_rows <= 0) return EGO_OK;
+    if (V % 8 || ld % 8 || n_mods <= 0 || V > 65536) return EGO_ERR_ARG;      // a row must fit the registers of one workgroup
+    if (V <= 2048) {
+        EGO_LAUNCH(ce_fwd_bwd_kernel<1>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods);
+    } else {
+        EGO_LAUNCH(ce_fwd_bwd_kernel<32>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods);
+    }
     LAUNCH_CHECK();
     return EGO_OK;
 }

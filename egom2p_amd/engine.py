@@ -80,6 +80,7 @@ class Engine:
         self._alloc_workspaces()
         self.weights_dirty = True
         self._have_fwd = False
+        self._ce_done, self._ce_grad = set(), None      # modalities whose CE backward ran inside the forward (loss_grad)
         self.max_graphs = 16                  # captured generation passes kept alive at once (LRU)
         self._iw, self._infer_key = None, None
         # optional: weight-gradient GEMMs on a side stream beside the dgrad / attention chain of the same layer, joined
@@ -501,9 +502,13 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
-                need_loss: bool = True, group_rows: bool = True):
+                need_loss: bool = True, group_rows: bool = True, loss_grad=None):
         """Forward of one micro-batch (tensors already on the device).  Returns (loss, {mod: loss}) as
-        views of a device buffer: reading them is the only host sync."""
+        views of a device buffer: reading them is the only host sync.
+        loss_grad (float or 1-element device tensor, optional): the upstream d loss the following `backward` will be
+        called with.  A training step knows it when the loss is formed, and the cross-entropy then runs forward and
+        backward in ONE pass over the logits (`ego_ce_fwd_bwd`: bitwise the two-call result, the 16.5 GB of logits of a
+        64-clip micro-batch are read once instead of twice); `backward` must then be given the same value."""
         if self.weights_dirty:
             self.refresh_weights()
         cfg, D, Fp, N, M = self.cfg, self.D, self.Fp, self.N, self.M
@@ -589,12 +594,20 @@ class Engine:
             return None
 
         # ---- per-modality logits + CE (forward_mod_loss, egom2p_model.py:614-644)
+        self._ce_done, self._ce_grad = set(), loss_grad
+        if loss_grad is not None:
+            self._set_gscale(loss_grad)
         for c, m in enumerate(mods):
             l = self.lin[self.logit_key[m.name]]
             ub = min(RM, B * m.max_tokens)
             lg = self.logits[m.vocab_size]
             ops.gemm_nt(self.yn, l.wb, lg, ub, m.vocab_size, D, L.EPI_BF16, m_range=self.ranges[c], lda=D, ldb=D, ldc=m.vocab_size)
-            ops.ce_fwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll)
+            if loss_grad is not None and ops.ce_fusable(m.vocab_size):
+                ops.ce_fwd_bwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll, self.gscale,
+                               self.n_mods)
+                self._ce_done.add(c)
+            else:
+                ops.ce_fwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll)
         # a decoder_attention_mask that is not one interval per row (compaction flag) turns the loss into NaN
         ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out, err=cd["err"])
         return self.loss_out[0], {m.name: self.loss_out[1 + c] for c, m in enumerate(mods)}
@@ -631,6 +644,12 @@ class Engine:
                           dx_in=dres, dx_bf16=nb)
         return nb
 
+    def _set_gscale(self, gscale):
+        if isinstance(gscale, torch.Tensor):
+            self.gscale.copy_(gscale.reshape(1).to(F32))
+        else:
+            self.gscale.fill_(float(gscale))
+
     def backward(self, gscale=1.0, bucket_done: Optional[Callable[[str, int, int], None]] = None):
         """Backward of the last forward; gradients are ACCUMULATED into the flat grad buffer scaled by
         `gscale` (float or 1-element device tensor: the upstream d loss).  `bucket_done(name, lo, hi)` is
@@ -639,10 +658,14 @@ class Engine:
         cfg, D, N, M, B = self.cfg, self.D, self.N, self.M, self.B
         RN, RM = B * N, B * M
         mods, ce, cd = self.mods, self.ce, self.cd
-        if isinstance(gscale, torch.Tensor):
-            self.gscale.copy_(gscale.reshape(1).to(F32))
+        if getattr(self, "_ce_done", None):
+            # the forward already turned the logits into d logits with the upstream gradient it was promised
+            same = (gscale is self._ce_grad) or (not isinstance(gscale, torch.Tensor) and not isinstance(self._ce_grad, torch.Tensor)
+                                                 and float(gscale) == float(self._ce_grad))
+            if not same:
+                raise L.EgoHipError("backward(gscale) differs from the loss_grad the forward was given")
         else:
-            self.gscale.fill_(float(gscale))
+            self._set_gscale(gscale)
         bmap = {n: (lo, hi) for n, lo, hi in self.buckets}
 
         def done(name):
@@ -657,7 +680,8 @@ class Engine:
             ub = min(RM, B * m.max_tokens)
             V = m.vocab_size
             lg = self.logits[V]
-            ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods)
+            if c not in self._ce_done:
+                ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods)
             ops.gemm_nt(lg, l.wt, self.dyn, ub, D, V, L.EPI_BF16, m_range=self.ranges[c], lda=V, ldb=V, ldc=D)
             self._wgrad(l.g, lg, self.yn, V, D, ub, ldp=V, ldq=D, m_range=self.ranges[c])
         for m in reversed(mods):
@@ -721,6 +745,7 @@ class Engine:
             done(f"enc_table.{m.name}")
         self._join_side()
         self._have_fwd = False
+        self._ce_done = set()
 
     def zero_grad(self):
         self.G.zero_()

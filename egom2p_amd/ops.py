@@ -197,6 +197,16 @@ def ce_bwd(logits, ld, V, targets, rng, max_rows, lse, gscale, n_mods):
           "ego_ce_bwd")
 
 
+def ce_fusable(V):
+    """ego_ce_fwd_bwd holds a logits row in one workgroup's registers"""
+    return V % 8 == 0 and V <= 65536
+
+
+def ce_fwd_bwd(logits, ld, V, targets, rng, max_rows, lse, nll, gscale, n_mods):
+    check(L.load().ego_ce_fwd_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(nll), _p(gscale), n_mods,
+                                  _stream()), "ego_ce_fwd_bwd")
+
+
 def loss_finalize(nll, ranges, n_mods, out, err=None):
     check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _p(err), _stream()), "ego_loss_finalize")
 

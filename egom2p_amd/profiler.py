@@ -135,7 +135,7 @@ class KernelTimer:
             "gemm_nt_fp8": c_gemm_nt_fp8, "gemm_nt_swiglu_fwd_fp8": c_gemm_nt_swiglu_fwd_fp8, "quant_fp8_rows": c_quant,
             "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_nt_swiglu_fwd": c_gemm_nt_swiglu_fwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
             "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
-            "ce_fwd": c_ce, "ce_bwd": c_ce_bwd,
+            "ce_fwd": c_ce, "ce_bwd": c_ce_bwd, "ce_fwd_bwd": c_ce_bwd,          # fused: one read + one write of the logits
         }
         # HBM-bound front-end / bookkeeping kernels: algorithmic bytes (the index streams once, only
         # the kept rows of the tables / positional tables, every output once)

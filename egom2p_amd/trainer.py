@@ -60,7 +60,7 @@ class TrainStep:
         self.loss_sum.zero_()
         for i, mb in enumerate(micro_batches):
             order = self.rng.sample(names, len(names))
-            eng.forward(mb, dec_order=order)
+            eng.forward(mb, dec_order=order, loss_grad=1.0 / k)      # the CE forms d logits in the same pass
             self.loss_sum += eng.loss_out
             last = i == k - 1
             eng.backward(1.0 / k, bucket_done=self.reducer.on_bucket if (last and self.reducer is not None) else None)

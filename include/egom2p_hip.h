@@ -227,6 +227,12 @@ int ego_ce_fwd(const void* logits, long ld, int V, const int* targets, const int
                float* nll, hipStream_t stream);
 int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, const float* lse,
                const float* gscale, int n_mods, hipStream_t stream);
+/* ego_ce_fwd and ego_ce_bwd in one pass over the logits (the training step knows the upstream gradient `gscale` when it
+ * forms the loss): lse / nll as ego_ce_fwd writes them, the logits overwritten as ego_ce_bwd does, bitwise the two-call
+ * result; the rows are read once.  V <= 65536 (a row is held in one workgroup's registers), else EGO_ERR_ARG: the caller
+ * then uses the two calls. */
+int ego_ce_fwd_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse, float* nll,
+                   const float* gscale, int n_mods, hipStream_t stream);
 /* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality.
  * err (optional): ego_compact's flag word; if set, every output is NaN (the reference's non-finite-loss exit,
  * run_training_egom2p.py:731-734, then stops the run instead of training on a wrong attention mask) and it is cleared. */

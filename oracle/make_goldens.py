@@ -6,7 +6,7 @@ four hot-path files are loaded by file path under empty namespace stubs, as SURV
 describes.  Nothing from the reference is copied: this script *calls* its code and stores
 input-independent data (outputs on generator-made weights and clips) as fixtures.
 
-    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b12]
+    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b12|L24]
 
 Weights/clips come from `egom2p_amd.synth` (counter-based generator) so the GPU box can
 regenerate them bit-identically; fixtures hold integer outputs in full and float outputs as
@@ -271,6 +271,12 @@ CASES = {
     # full-depth ego-b (400M), canonical split, B=1
     "b12": dict(cfg_name="egom2p_base_12e_12d_swiglu_nobias", batch=1, n_enc=2048, n_dec=2048, budgets=None,
                 seed=5, full_float=False, py_seed=15),
+    # full-depth ego-L at the throughput shape (BASELINE config 5: D = 1152, 18 heads of 64, F = 3072, 24 + 24 layers,
+    # 1.19 B parameters), canonical split, B=1
+    # (N = M = 1024: the fp32 autograd graph of 48 layers at 2048 x 2048 scores does not fit this container's 64 GB)
+    "L24": dict(cfg_name="ego_L_1152", batch=1, n_enc=1024, n_dec=1024,
+                budgets={"tok_rgb": (497, 497), "tok_depth": (497, 497), "tok_cam": (15, 15), "tok_gaze": (15, 15)},
+                seed=9, full_float=False, py_seed=19),
 }
 
 

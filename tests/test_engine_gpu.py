@@ -12,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from conftest import load_golden, rel_l2  # noqa: E402
+from egom2p_amd import _lib as L  # noqa: E402
 from egom2p_amd import ops, synth  # noqa: E402
 from egom2p_amd.config import MODEL_CFGS  # noqa: E402
 from egom2p_amd.engine import Engine  # noqa: E402
@@ -43,7 +44,7 @@ def _tap(g, key, t):
     return max(e1, e2, e3)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim
@@ -228,6 +229,33 @@ def test_full_size_step_agrees_across_kernel_families():
         hi = min(n, lo + n // 16)
         d = float((g1[lo:hi] - g0[lo:hi]).double().norm() / max(float(g0[lo:hi].double().norm()), 1e-30))
         assert d < 1e-2, (lo, hi, d)
+
+
+def test_forward_with_loss_grad_equals_the_two_pass_cross_entropy():
+    """`forward(loss_grad=g)` (the training step: cross-entropy forward + backward in one pass over the logits) followed by
+    `backward(g)` leaves bit for bit the losses and gradients of `forward()` + `backward(g)`; a different `g` in the
+    backward is refused (the logits already hold d logits for the promised one)."""
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=3, n_enc=2048, n_dec=2048)
+    eng.init_random(7)
+    md = synth.make_clip_batch_device(cfg, 3, synth.dirichlet_budgets(cfg, 3, 2048, 2048, 4), seed=4, sample_offset=0, device="cuda:0")
+    order = [m.name for m in reversed(cfg.mods)]
+    eng.zero_grad()
+    loss, mod_loss = eng.forward(md, dec_order=order)
+    eng.backward(0.25)
+    l2, m2, g2 = loss.clone(), {k: v.clone() for k, v in mod_loss.items()}, eng.G.clone()
+    eng.zero_grad()
+    loss, mod_loss = eng.forward(md, dec_order=order, loss_grad=0.25)
+    with pytest.raises(L.EgoHipError):
+        eng.backward(0.5)
+    eng.backward(0.25)
+    assert torch.equal(loss, l2) and all(torch.equal(mod_loss[k], m2[k]) for k in m2)
+    assert torch.equal(eng.G, g2)
+    # and the next plain forward / backward is unaffected by the earlier promise
+    eng.zero_grad()
+    eng.forward(md, dec_order=order)
+    eng.backward(0.25)
+    assert torch.equal(eng.G, g2)
 
 
 def test_micro_batch_64_equals_two_accumulated_halves():

@@ -430,6 +430,32 @@ def test_cross_entropy():
     assert torch.equal(logits[:40], keep[:40]) and torch.equal(logits[240:], keep[240:])
 
 
+@pytest.mark.parametrize("V", [64000, 256, 65536, 2056])
+def test_cross_entropy_one_pass_equals_the_two_calls(V):
+    """ego_ce_fwd_bwd (training: forward and backward of the CE in one pass over the logits) writes bit for bit what
+    ego_ce_fwd followed by ego_ce_bwd writes; rows outside the range stay untouched; V > 65536 is refused."""
+    n_total = 300
+    logits = _bf(torch.randn(n_total, V, device=DEV) * 3)
+    tgt = torch.randint(0, V, (n_total,), device=DEV, dtype=torch.int32)
+    tgt[41], tgt[42] = 0, V - 1
+    rng = torch.tensor([40, 200], device=DEV, dtype=torch.int32)
+    g = torch.tensor([0.25], device=DEV)
+    two = logits.clone()
+    lse2, nll2 = torch.zeros(n_total, device=DEV), torch.zeros(n_total, device=DEV)
+    ops.ce_fwd(two, V, V, tgt, rng, 260, lse2, nll2)
+    ops.ce_bwd(two, V, V, tgt, rng, 260, lse2, g, 4)
+    one = logits.clone()
+    lse1, nll1 = torch.zeros(n_total, device=DEV), torch.zeros(n_total, device=DEV)
+    assert ops.ce_fusable(V)
+    ops.ce_fwd_bwd(one, V, V, tgt, rng, 260, lse1, nll1, g, 4)
+    assert torch.equal(lse1, lse2) and torch.equal(nll1, nll2)
+    assert torch.equal(one, two)
+    assert torch.equal(one[:40], logits[:40]) and torch.equal(one[240:], logits[240:])
+    assert not ops.ce_fusable(65544)
+    with pytest.raises(L.EgoHipError):
+        ops.ce_fwd_bwd(one, 65544, 65544, tgt, rng, 1, lse1, nll1, g, 4)
+
+
 def test_bias_grad_and_cast():
     g = _bf(torch.randn(1000, 768, device=DEV))
     db = torch.zeros(768, device=DEV)

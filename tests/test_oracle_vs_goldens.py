@@ -20,7 +20,7 @@ FP32_TOL = 2e-5
 
 CASES = ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged"]
 if os.environ.get("EGOM2P_SLOW") == "1":
-    CASES += ["b12", "L2"]
+    CASES += ["b12", "L2", "L24"]
 
 
 def _setup(case):
