@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOM2P_HIP_LIB", os.path.join(_HERE, "libegom2p_hip.so"))   # override: kernel experiments
 MAX_MODS = 8
 
-ABI_VERSION = 3          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
+ABI_VERSION = 4          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
 EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -65,9 +65,9 @@ _SIGS = {
     "ego_rows_gather": [vp, vp, vp, i32, i32, vp, vp],
     "ego_rows_scatter": [vp, vp, vp, i32, i32, vp, i32, vp],
     "ego_loss_perm": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
-    "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, i64, vp, vp],
+    "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, vp, i64, vp, vp],
     "ego_layernorm_bwd_work_floats": [i32, i32],
-    "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "ego_quant_fp8_rows": [vp, i64, i64, i32, vp, i64, vp, vp],
@@ -78,6 +78,10 @@ _SIGS = {
                          i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
                          vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
+    "ego_attn_fwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64,
+                        i32, i32, i32, i32, i32, f32, vp],
+    "ego_attn_bwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
+                        vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, i32, f32, vp],
     "ego_budget_dirichlet": [C.POINTER(BudgetDesc), vp, i32, vp, vp, vp],
     "ego_clip_synth": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "ego_swiglu_fwd": [vp, vp, i64, i32, vp],

@@ -92,6 +92,9 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     "ego_b_2e_2d_untied": ModelCfg("ego_b_2e_2d_untied", 768, 2, 2, 12, share_embedding=False),
     "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
     "ego_L_1152_2e_2d": ModelCfg("ego_L_1152_2e_2d", 1152, 2, 2, 18),       # ego-L width (BASELINE config 5) at parity-test depth
+    # the REGISTERED ego-L geometry (egom2p_model.py:1080-1092: dim 1020, 15 heads of 68, F = 2720) at parity-test depth;
+    # stored in rows of 1024 with heads padded to 128 (engine.py) and run by the ego_attn_*_hd kernels
+    "ego_L_1020_2e_2d": ModelCfg("ego_L_1020_2e_2d", 1020, 2, 2, 15),
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),
     # config 4 (rgb -> depth generation) at ego-b width: D = 768, 12 heads of 64, F = 2048, at parity-test depth
     "ego_b_gen_2e_2d": ModelCfg("ego_b_gen_2e_2d", 768, 2, 2, 12, modalities=("tok_rgb", "tok_depth")),

@@ -1,0 +1,442 @@
+// Attention for head dimensions other than 64 - the registered ego-L (egom2p_model.py:1080-1092: D = 1020, 15 heads of 68).
+// A head is stored padded with zero columns to HDP = 96 or 128 (MFMA 32x32x16: the contraction runs in steps of 16, the
+// output in blocks of 32), so the scores and the outputs are those of the unpadded head.  Same semantics as the d64
+// kernels (attention.hip): one [ks, ke) key interval per query row (or per sample), an empty interval = uniform attention
+// over all Nk keys with a zero score scale, rows / keys past Nq / Nk do not exist.
+//
+// These are the PARITY kernels of a configuration nobody trains at scale (only the 400 M checkpoint is released): same
+// math and the same operand layouts as the d64 family - S^T = K Q'^T with the query on the lane, per-lane online softmax,
+// O^T = V^T P^T on key-permuted fragments - but tiles are staged through LDS with plain loads and __syncthreads (no LDS-DMA
+// ring, no lazy softmax reference), and every key / query tile is visited.  The throughput shapes (head dim 64) never come here.
+#include "common.h"
+#include "egom2p_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct HdArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;
+    bf16_t* O; long o_bs, o_rs;
+    bf16_t* Olo;
+    float* LSE;                 // [B,H,Nq] log2-domain log-sum-exp of the scaled scores
+    const int* ks; const int* ke;
+    long r_bs, r_rs;
+    int B, H, Nq, Nk;
+    float scale;
+    const bf16_t* dO; long do_bs, do_rs;
+    float* DELTA;               // [B,H,Nq] rowsum(dO o O)
+    bf16_t* dQ; long dq_bs, dq_rs;
+    bf16_t* dK; long dk_bs, dk_rs;
+    bf16_t* dV; long dv_bs, dv_rs;
+};
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int x) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * x + j];
+    return r;
+}
+
+// LDS tiles of 32 rows (keys or queries):
+//   natural    [32][HDP] bf16, row pitch HDP * 2 + 16 bytes - a lane reads its row's 16-byte fragment per k-step
+//   transposed [HDP][32] bf16, row pitch 80 bytes           - a lane reads dims' two 8-byte key groups per 16-key step
+template <int HDP> struct Tile {
+    static constexpr int NPITCH = HDP * 2 + 16, TPITCH = 80;
+    static constexpr int NBYTES = 32 * NPITCH, TBYTES = HDP * TPITCH;
+    static constexpr int CHUNKS = 32 * (HDP / 8);              // 16-byte chunks of a tile
+};
+
+// rows [row0, row0 + 32) of a [nrows, *] bf16 matrix (row stride rs elements) -> natural and / or transposed tile; rows
+// past nrows read as zeros
+template <int HDP, bool NAT, bool TRN>
+__device__ __forceinline__ void load_tile(const bf16_t* base, long rs, int row0, int nrows, char* nat, char* trn, int tid) {
+    typedef Tile<HDP> T;
+    for (int c = tid; c < T::CHUNKS; c += 256) {
+        const int row = c / (HDP / 8), ch = c % (HDP / 8);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + row < nrows) v = *(const u32x4*)(base + (long)(row0 + row) * rs + ch * 8);
+        if (NAT) *(u32x4*)(nat + row * T::NPITCH + ch * 16) = v;
+        if (TRN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *(bf16_t*)(trn + (ch * 8 + 2 * e) * T::TPITCH + row * 2) = (bf16_t)(v[e] & 0xffff);
+                *(bf16_t*)(trn + (ch * 8 + 2 * e + 1) * T::TPITCH + row * 2) = (bf16_t)(v[e] >> 16);
+            }
+        }
+    }
+}
+
+// A fragment of the transposed tile for output block db, 16-row step x: dims row 32 db + (lane & 31), rows
+// {16x + 4hh .. +3} and {16x + 8 + 4hh .. +3} - the row permutation pack8() gives the B operand
+template <int HDP>
+__device__ __forceinline__ bf16x8 trn_frag(const char* trn, int db, int x, int lane) {
+    typedef Tile<HDP> T;
+    const int hh = lane >> 5;
+    const char* p = trn + (32 * db + (lane & 31)) * T::TPITCH + (16 * x + 4 * hh) * 2;
+    const u32x2 lo = *(const u32x2*)p, hi = *(const u32x2*)(p + 16);
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int HDP>
+__device__ __forceinline__ bf16x8 nat_frag(const char* nat, int s, int lane) {
+    typedef Tile<HDP> T;
+    return *(const bf16x8*)(nat + (lane & 31) * T::NPITCH + (16 * s + 8 * (lane >> 5)) * 2);
+}
+
+// transposed accumulators [HDP dims][32 rows on lanes] -> bf16 rows
+template <int HDP>
+__device__ __forceinline__ void store_rows(bf16_t* dst, bf16_t* lo, const f32x16 (&t)[HDP / 32], float mul, int hh) {
+#pragma unroll
+    for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + 8 * g + 4 * hh;
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = t[db][4 * g + e] * mul;
+            const u32x2 o = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+            *(u32x2*)(dst + d0) = o;
+            if (lo) {
+                const u32x2 q = {pack_bf16x2(x[0] - round_bf16(x[0]), x[1] - round_bf16(x[1])),
+                                 pack_bf16x2(x[2] - round_bf16(x[2]), x[3] - round_bf16(x[3]))};
+                *(u32x2*)(lo + d0) = q;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: workgroup = 128 queries of one (batch, head), wave = 32 of them (query on the lane)
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
+    typedef Tile<HDP> T;
+    constexpr int KS = HDP / 16, DB = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Vt[T::TBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.Nq + 127) >> 7;
+    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int h = pair % p.H, b = pair / p.H;
+    const int q0 = tile * 128 + wave * 32, ql = lane & 31, hh = lane >> 5;
+    const int qrow = min(q0 + ql, p.Nq - 1);
+    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
+    float sc = p.scale * LOG2E;
+    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
+
+    const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * HDP;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 qr = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qr[e] * sc);
+    }
+    const bf16_t* Kb = p.K + (long)b * p.k_bs + h * HDP;
+    const bf16_t* Vb = p.V + (long)b * p.v_bs + h * HDP;
+
+    f32x16 ot[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[db][i] = 0.f;
+    float m = NEG_BIG, l = 0.f;
+    const int nkt = (p.Nk + 31) >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        load_tile<HDP, true, false>(Kb, p.k_rs, kt * 32, p.Nk, Kn, nullptr, tid);
+        load_tile<HDP, false, true>(Vb, p.v_rs, kt * 32, p.Nk, nullptr, Vt, tid);
+        __syncthreads();
+        f32x16 st;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kidx = kt * 32 + acc_row(r, hh);
+            const float v = (kidx >= ks && kidx < ke) ? st[r] : NEG_BIG;
+            st[r] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = xhalf_max(mx);
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);       // (both NEG_BIG: 1, with l = 0 and O = 0)
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ot[db][i] *= alpha;
+        m = mnew;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pe = (st[r] <= NEG_BIG) ? 0.f : __builtin_amdgcn_exp2f(st[r] - mnew);
+            rs += pe;
+            st[r] = pe;
+        }
+        l += rs;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8 pf = pack8(st, x);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Vt, db, x, lane), pf, ot[db], 0, 0, 0);
+        }
+    }
+    const float lt = xhalf_sum(l);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    if (q0 + ql < p.Nq) {
+        const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * HDP;
+        store_rows<HDP>(p.O + oo, p.Olo ? p.Olo + oo : nullptr, ot, inv, hh);
+        if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = m + __builtin_amdgcn_logf(lt);       // v_log_f32 = log2
+    }
+}
+
+// delta[b,h,q] = rowsum(dO o (O + O_lo)): one thread per (batch, head, query)
+template <int HDP>
+__global__ __launch_bounds__(256) void hd_delta_kernel(HdArgs p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)p.B * p.H * p.Nq) return;
+    const int q = (int)(i % p.Nq), h = (int)((i / p.Nq) % p.H), b = (int)(i / ((long)p.Nq * p.H));
+    const bf16_t* g = p.dO + (long)b * p.do_bs + (long)q * p.do_rs + h * HDP;
+    const long oo = (long)b * p.o_bs + (long)q * p.o_rs + h * HDP;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HDP / 8; ++c) {
+        const u32x4 gv = *(const u32x4*)(g + 8 * c), ov = *(const u32x4*)(p.O + oo + 8 * c);
+        u32x4 lv = {0u, 0u, 0u, 0u};
+        if (p.Olo) lv = *(const u32x4*)(p.Olo + oo + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s += bf16_to_f32(gv[e] & 0xffff) * (bf16_to_f32(ov[e] & 0xffff) + bf16_to_f32(lv[e] & 0xffff));
+            s += bf16_to_f32(gv[e] >> 16) * (bf16_to_f32(ov[e] >> 16) + bf16_to_f32(lv[e] >> 16));
+        }
+    }
+    p.DELTA[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, query-major: dQ = scale * sum_k dS K,  dS = P o (dP - delta)
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
+    typedef Tile<HDP> T;
+    constexpr int KS = HDP / 16, DB = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Vn[T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Kt[T::TBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.Nq + 127) >> 7;
+    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int h = pair % p.H, b = pair / p.H;
+    const int q0 = tile * 128 + wave * 32, ql = lane & 31, hh = lane >> 5;
+    const int qrow = min(q0 + ql, p.Nq - 1);
+    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
+    float sc = p.scale * LOG2E, gsc = p.scale;
+    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
+    const long li = ((long)b * p.H + h) * p.Nq + qrow;
+    const float lse2 = p.LSE[li], delta = p.DELTA[li];
+
+    const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * HDP;
+    const bf16_t* Gp = p.dO + (long)b * p.do_bs + (long)qrow * p.do_rs + h * HDP;
+    bf16x8 qf[KS], gf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 qr = *(const bf16x8*)(Qp + 16 * s + 8 * hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qr[e] * sc);
+        gf[s] = *(const bf16x8*)(Gp + 16 * s + 8 * hh);
+    }
+    const bf16_t* Kb = p.K + (long)b * p.k_bs + h * HDP;
+    const bf16_t* Vb = p.V + (long)b * p.v_bs + h * HDP;
+
+    f32x16 dqt[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqt[db][i] = 0.f;
+    const int nkt = (p.Nk + 31) >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        load_tile<HDP, true, true>(Kb, p.k_rs, kt * 32, p.Nk, Kn, Kt, tid);
+        load_tile<HDP, true, false>(Vb, p.v_rs, kt * 32, p.Nk, Vn, nullptr, tid);
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Vn, s, lane), gf[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kidx = kt * 32 + acc_row(r, hh);
+            const float pe = (kidx >= ks && kidx < ke) ? __builtin_amdgcn_exp2f(st[r] - lse2) : 0.f;
+            st[r] = pe * (dp[r] - delta);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8 df = pack8(st, x);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Kt, db, x, lane), df, dqt[db], 0, 0, 0);
+        }
+    }
+    if (q0 + ql < p.Nq)
+        store_rows<HDP>(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * HDP, nullptr, dqt, gsc, hh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, key-major: dV = P^T dO,  dK = scale * dS^T Q (workgroup = 128 keys, wave = 32 of them, key on the lane)
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
+    typedef Tile<HDP> T;
+    constexpr int KS = HDP / 16, DB = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char Qn[T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Gn[T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Qt[T::TBYTES];
+    __shared__ __attribute__((aligned(16))) char Gt[T::TBYTES];
+    __shared__ float a_lse[32], a_delta[32];
+    __shared__ int a_ks[32], a_ke[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.Nk + 127) >> 7;
+    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int h = pair % p.H, b = pair / p.H;
+    const int kl = lane & 31, hh = lane >> 5;
+    const int kidx = tile * 128 + wave * 32 + kl;
+    const int krow = min(kidx, p.Nk - 1);
+    const float c_sc = p.scale * LOG2E;
+    const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)krow * p.k_rs + h * HDP;
+    const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)krow * p.v_rs + h * HDP;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 kr = *(const bf16x8*)(Kp + 16 * s + 8 * hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kf[s][e] = (__bf16)((float)kr[e] * c_sc);
+        vf[s] = *(const bf16x8*)(Vp + 16 * s + 8 * hh);
+    }
+    const bf16_t* Qb = p.Q + (long)b * p.q_bs + h * HDP;
+    const bf16_t* Gb = p.dO + (long)b * p.do_bs + h * HDP;
+    const long lb = ((long)b * p.H + h) * p.Nq;
+
+    f32x16 dkt[DB], dvt[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkt[db][i] = 0.f; dvt[db][i] = 0.f; }
+    const int nqt = (p.Nq + 31) >> 5;
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        load_tile<HDP, true, true>(Qb, p.q_rs, qt * 32, p.Nq, Qn, Qt, tid);
+        load_tile<HDP, true, true>(Gb, p.do_rs, qt * 32, p.Nq, Gn, Gt, tid);
+        if (tid < 32) {
+            const int q = qt * 32 + tid;
+            const bool in = q < p.Nq;
+            const int qc = min(q, p.Nq - 1);
+            a_lse[tid] = p.LSE[lb + qc];
+            a_delta[tid] = p.DELTA[lb + qc];
+            int rks = p.ks[b * p.r_bs + qc * p.r_rs], rke = min(p.ke[b * p.r_bs + qc * p.r_rs], p.Nk);
+            if (!in) { rks = 0x7fffffff; rke = -1; }                    // a row past Nq sees no key (and is not "flat")
+            a_ks[tid] = rks; a_ke[tid] = rke;
+        }
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Qn, s, lane), kf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Gn, s, lane), vf[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = acc_row(r, hh);
+            int rks = a_ks[q], rke = a_ke[q];
+            const bool past = rke < 0;
+            const bool flat = !past && rke <= rks;                      // empty interval: p = 1 / Nk, dS = 0
+            if (flat) { rks = 0; rke = p.Nk; }
+            const bool ok = !past && kidx >= rks && kidx < rke && kidx < p.Nk;
+            const float pe = ok ? __builtin_amdgcn_exp2f((flat ? 0.f : st[r]) - a_lse[q]) : 0.f;
+            st[r] = pe;
+            dp[r] = flat ? 0.f : pe * (dp[r] - a_delta[q]);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8 pf = pack8(st, x), df = pack8(dp, x);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Gt, db, x, lane), pf, dvt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Qt, db, x, lane), df, dkt[db], 0, 0, 0);
+            }
+        }
+    }
+    if (kidx < p.Nk) {
+        store_rows<HDP>(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * HDP, nullptr, dkt, p.scale, hh);
+        store_rows<HDP>(p.dV + (long)b * p.dv_bs + (long)krow * p.dv_rs + h * HDP, nullptr, dvt, 1.f, hh);
+    }
+}
+
+bool check(const HdArgs& a, int hdp) {
+    return (hdp == 96 || hdp == 128) && a.B > 0 && a.H > 0 && a.Nq > 0 && a.Nk > 0 && a.q_rs % 8 == 0 && a.k_rs % 8 == 0 &&
+           a.v_rs % 8 == 0 && a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0 && a.o_rs % 8 == 0 && a.o_bs % 8 == 0;
+}
+
+}  // namespace
+
+extern "C" int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V,
+                               long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks,
+                               const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk, int hd_pad, float scale,
+                               hipStream_t stream) {
+    HdArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a, hd_pad)) return EGO_ERR_ARG;
+    const dim3 grid(B * H * ((Nq + 127) / 128));
+    if (hd_pad == 96) { EGO_LAUNCH(hd_fwd_kernel<96>, grid, dim3(256), 0, stream, a); }
+    else { EGO_LAUNCH(hd_fwd_kernel<128>, grid, dim3(256), 0, stream, a); }
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_attn_bwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V,
+                               long v_bs, long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo, const void* dO,
+                               long do_bs, long do_rs, const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs,
+                               void* dK, long dk_bs, long dk_rs, void* dV, long dv_bs, long dv_rs, const int* ks,
+                               const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk, int hd_pad, float scale,
+                               hipStream_t stream) {
+    HdArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo;
+    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA;
+    a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
+    a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
+    a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a, hd_pad) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4) return EGO_ERR_ARG;
+    const long rows = (long)B * H * Nq;
+    const dim3 gq(B * H * ((Nq + 127) / 128)), gk(B * H * ((Nk + 127) / 128)), gd((unsigned)((rows + 255) / 256));
+    if (hd_pad == 96) {
+        EGO_LAUNCH(hd_delta_kernel<96>, gd, dim3(256), 0, stream, a);
+        EGO_LAUNCH(hd_dq_kernel<96>, gq, dim3(256), 0, stream, a);
+        EGO_LAUNCH(hd_dkv_kernel<96>, gk, dim3(256), 0, stream, a);
+    } else {
+        EGO_LAUNCH(hd_delta_kernel<128>, gd, dim3(256), 0, stream, a);
+        EGO_LAUNCH(hd_dq_kernel<128>, gq, dim3(256), 0, stream, a);
+        EGO_LAUNCH(hd_dkv_kernel<128>, gk, dim3(256), 0, stream, a);
+    }
+    LAUNCH_CHECK();
+    return EGO_OK;
+}

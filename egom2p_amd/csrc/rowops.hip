@@ -18,13 +18,15 @@ template <int LN_MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, const int* __restrict__ out_row,
-                                                     int rows, int D, float eps, unsigned char* __restrict__ q8, long ldq,
+                                                     int rows, int D, int ld, float eps, unsigned char* __restrict__ q8, long ldq,
                                                      float* __restrict__ qscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int nc = D >> 2;
-    const float* xr = x + (long)row * D;
+    // D = the normalised width, ld >= D = the row pitch of x and y (a model dimension stored padded: the columns [D, ld) of
+    // x are zero and do not take part; those of y are written as zeros)
+    const int nc = D >> 2, ncl = ld >> 2;
+    const float* xr = x + (long)row * ld;
     f32x4 v[LN_MAXC];
     float s = 0.f;
 #pragma unroll
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     const int orow = out_row ? out_row[row] : row;
     if (orow < 0) return;
-    bf16_t* yr = y + (long)orow * D;
+    bf16_t* yr = y + (long)orow * ld;
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
@@ -57,6 +59,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int e = 0; e < 4; ++e) { v[i][e] = round_bf16((v[i][e] - mean) * rstd * ww[e]); amax = fmaxf(amax, fabsf(v[i][e])); }
             u32x2 o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3])};
             *(u32x2*)(yr + c * 4) = o;
+        } else if (c < ncl) {
+            *(u32x2*)(yr + c * 4) = u32x2{0u, 0u};
         }
     }
     // optional e4m3 copy of the row for an fp8 GEMM (bit for bit what ego_quant_fp8_rows makes of the bf16 row)
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ w,
                                                      const float* dx_in, float* dx_out, bf16_t* dx_bf16,
-                                                     float* __restrict__ dw_part, int rows, int D) {
+                                                     float* __restrict__ dw_part, int rows, int D, int ld) {
     __shared__ float red[4][LN_MAXC * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nc = D >> 2;
+    const int nc = D >> 2, ncl = ld >> 2;      // D = normalised width, ld = row pitch (columns [D, ld): zero gradient)
     f32x4 ww[LN_MAXC], dwa[LN_MAXC];
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         if (row >= rows) break;
         const int grow = dy_row ? dy_row[row] : row;
         const float mean = mean_in[row], rstd = rstd_in[row];
-        const float* xr = x + (long)row * D;
+        const float* xr = x + (long)row * ld;
         f32x4 g[LN_MAXC], xh[LN_MAXC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 const f32x4 xv = *(const f32x4*)(xr + c * 4);
                 f32x4 d = {0.f, 0.f, 0.f, 0.f};
                 if (grow >= 0) {
-                    const u32x2 raw = *(const u32x2*)(dy + (long)grow * D + c * 4);
+                    const u32x2 raw = *(const u32x2*)(dy + (long)grow * ld + c * 4);
                     d = f32x4{bf16_to_f32(raw[0] & 0xffff), bf16_to_f32(raw[0] >> 16), bf16_to_f32(raw[1] & 0xffff), bf16_to_f32(raw[1] >> 16)};
                 }
 #pragma unroll
@@ -136,12 +140,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
-                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * D + c * 4);
-                *(f32x4*)(dx_out + (long)row * D + c * 4) = o;
+                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * ld + c * 4);
+                *(f32x4*)(dx_out + (long)row * ld + c * 4) = o;
                 if (dx_bf16) {
                     u32x2 b = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                    *(u32x2*)(dx_bf16 + (long)row * D + c * 4) = b;
+                    *(u32x2*)(dx_bf16 + (long)row * ld + c * 4) = b;
                 }
+            } else if (c < ncl) {
+                *(f32x4*)(dx_out + (long)row * ld + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (dx_bf16) *(u32x2*)(dx_bf16 + (long)row * ld + c * 4) = u32x2{0u, 0u};
             }
         }
     }
@@ -562,13 +569,13 @@ __attribute__((visibility("hidden"))) long colsum_work_floats(long n, int W) {  
 
 
 extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd,
-                                 const int* out_row, int rows, int D, float eps, void* q8, long ldq, float* qscale,
+                                 const int* out_row, int rows, int D, long ld, float eps, void* q8, long ldq, float* qscale,
                                  hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D % 4 || D > LN_MAXC_MAX * 256 || (q8 && (!qscale || ldq % 4))) return EGO_ERR_ARG;
-#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, eps, \
+    if (D <= 0 || D % 4 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || (q8 && (!qscale || ldq % 4 || ld != D))) return EGO_ERR_ARG;
+#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, (int)ld, eps, \
                              (unsigned char*)q8, ldq, qscale)
-    if (D <= 768) LN_FWD(3); else if (D <= 1024) LN_FWD(4); else if (D <= 1536) LN_FWD(6); else LN_FWD(8);
+    if (ld <= 768) LN_FWD(3); else if (ld <= 1024) LN_FWD(4); else if (ld <= 1536) LN_FWD(6); else LN_FWD(8);
 #undef LN_FWD
     LAUNCH_CHECK();
     return EGO_OK;
@@ -578,13 +585,15 @@ extern "C" long ego_layernorm_bwd_work_floats(int rows, int D) { return colsum_w
 
 extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float* x, const float* mean,
                                  const float* rstd, const float* w, const float* dx_in, float* dx_out,
-                                 void* dx_bf16, float* dw, float* work, long work_floats, int rows, int D, hipStream_t stream) {
+                                 void* dx_bf16, float* dw, float* work, long work_floats, int rows, int D, long ld,
+                                 hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D % 4 || D > LN_MAXC_MAX * 256 || !work || work_floats < ego_layernorm_bwd_work_floats(rows, D)) return EGO_ERR_ARG;
+    if (D <= 0 || D % 4 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || !work || work_floats < ego_layernorm_bwd_work_floats(rows, D))
+        return EGO_ERR_ARG;
     const int nwg = (rows + LNB_ROWS - 1) / LNB_ROWS;
 #define LN_BWD(C) EGO_LAUNCH(ln_bwd_kernel<C>, dim3(nwg), dim3(256), 0, stream, (const bf16_t*)dy, \
-                       dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, work, rows, D)
-    if (D <= 768) LN_BWD(3); else if (D <= 1024) LN_BWD(4); else if (D <= 1536) LN_BWD(6); else LN_BWD(8);
+                       dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, work, rows, D, (int)ld)
+    if (ld <= 768) LN_BWD(3); else if (ld <= 1024) LN_BWD(4); else if (ld <= 1536) LN_BWD(6); else LN_BWD(8);
 #undef LN_BWD
     LAUNCH_CHECK();
     ColsumDst dst{};

@@ -66,11 +66,27 @@ class Engine:
         if attn_o_residual not in ("cross", "all", "none"):
             raise ValueError("attn_o_residual must be 'cross', 'all' or 'none'")
         self.attn_o_residual = attn_o_residual
-        if cfg.dim % 128 or cfg.head_dim != 64:
-            raise L.EgoHipError(f"engine needs dim % 128 == 0 and head_dim == 64 (got dim={cfg.dim}, head_dim={cfg.head_dim})")
+        # Storage geometry.  D = the row pitch of every [rows, dim] activation and of every weight's model-dim axis: cfg.dim
+        # rounded up to 128 (GEMM K steps / tiles) with zero pad columns - equal to cfg.dim for ego-b and the 1152-wide
+        # ego-L; the REGISTERED ego-L (egom2p_model.py:1080-1092: dim 1020, 15 heads of 68) lives in rows of 1024.  Heads
+        # are stored HDP elements apart (64 -> 64: the throughput attention kernels; otherwise zero-padded to 96 or 128 for
+        # the ego_attn_*_hd kernels), A = H * HDP is the width of the q / k / v / attention-output rows.  Pad columns and
+        # pad weight rows are zero and stay zero: their gradients are exact zeros (zero operands), and AdamW maps (0, 0) to 0.
         self.cfg = cfg
         self.dev = torch.device(device)
-        self.D, self.H = cfg.dim, cfg.num_heads
+        self.Dl, self.D, self.H = cfg.dim, _pad128(cfg.dim), cfg.num_heads
+        self.HD = cfg.head_dim
+        if self.HD == 64:
+            self.HDP = 64
+        else:
+            fits = [h for h in (96, 128) if h >= self.HD and (self.H * h) % 128 == 0]
+            if cfg.dim % 4 or not fits:
+                raise L.EgoHipError(f"no storage layout for dim={cfg.dim}, heads={cfg.num_heads} x {self.HD}")
+            self.HDP = fits[0]
+        self.A = self.H * self.HDP
+        self.padded = self.D != self.Dl or self.HDP != self.HD
+        if self.padded and fp8_forward:
+            raise L.EgoHipError("the fp8 forward is built for the unpadded shapes (dim % 128 == 0, head_dim 64)")
         self.F, self.Fp = cfg.mlp_hidden, _pad128(cfg.mlp_hidden)
         self.mods: List[Modality] = cfg.mods
         self.n_mods = len(self.mods)
@@ -99,7 +115,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ parameters
     def _build_params(self):
-        D, Fp, cfg = self.D, self.Fp, self.cfg
+        D, A, Fp, cfg = self.D, self.A, self.Fp, self.cfg
         spec: List[Tuple[str, Tuple[int, ...]]] = []
         groups: List[Tuple[str, int, int]] = []      # (group name, lo, hi) = all-reduce buckets, forward order
 
@@ -111,14 +127,14 @@ class Engine:
             for n in norms:
                 add(f"{prefix}.{n}.weight", (D,))
             if kind == "enc":
-                add(f"{prefix}.attn.qkv.weight", (3 * D, D))
-                add(f"{prefix}.attn.proj.weight", (D, D))
+                add(f"{prefix}.attn.qkv.weight", (3 * A, D))
+                add(f"{prefix}.attn.proj.weight", (D, A))
             else:
-                add(f"{prefix}.self_attn.qkv.weight", (3 * D, D))
-                add(f"{prefix}.self_attn.proj.weight", (D, D))
-                add(f"{prefix}.cross_attn.q.weight", (D, D))
-                add(f"{prefix}.cross_attn.kv.weight", (2 * D, D))
-                add(f"{prefix}.cross_attn.proj.weight", (D, D))
+                add(f"{prefix}.self_attn.qkv.weight", (3 * A, D))
+                add(f"{prefix}.self_attn.proj.weight", (D, A))
+                add(f"{prefix}.cross_attn.q.weight", (A, D))
+                add(f"{prefix}.cross_attn.kv.weight", (2 * A, D))
+                add(f"{prefix}.cross_attn.proj.weight", (D, A))
             add(f"{prefix}.mlp.fc1.weight", (Fp, D))      # fc1 | fc3 adjacent: one fused [2Fp, D] GEMM operand
             add(f"{prefix}.mlp.fc3.weight", (Fp, D))
             add(f"{prefix}.mlp.fc2.weight", (D, Fp))
@@ -184,7 +200,11 @@ class Engine:
                 runs.append([o, o + n4, nd])
         self.opt_runs = [(a, b, nd) for a, b, nd in runs]
         # fixed positional tables (buffers)
-        self.pos = {m.name: build_pos_emb(m, D)[0].to(self.dev).contiguous() for m in self.mods}
+        self.pos = {}
+        for m in self.mods:
+            pe = torch.zeros(m.max_tokens, D, device=self.dev, dtype=F32)
+            pe[:, :self.Dl] = build_pos_emb(m, self.Dl)[0].to(self.dev)
+            self.pos[m.name] = pe
 
         # linear layers: bf16 copies
         self.lin: Dict[str, _Lin] = {}
@@ -226,12 +246,44 @@ class Engine:
             key = key.replace("decoder_embeddings", "encoder_embeddings")      # shared Parameter
         if key.endswith("to_logits.weight") and self.cfg.share_embedding:
             key = key.replace("to_logits.weight", "token_emb.weight")          # tied
-        t = self.p[key]
+        return self._logical(key, self.p[key])
+
+    def _logical(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        """The part of a storage tensor (parameter or gradient) that is the reference's tensor `key`: a view without the
+        zero padding.  Unpadded configurations: the tensor itself (fc1 / fc3 / fc2: without the F -> Fp pad).  Padded ones:
+        the model-dim axes cut to cfg.dim and the head axis split so that every head loses its pad columns - a strided view
+        of as many elements as the reference tensor, in its element order (`.reshape(reference shape)` gives the tensor)."""
+        F, Dl, H, HD, HDP = self.F, self.Dl, self.H, self.HD, self.HDP
         if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
-            return t[:F]
+            return t[:F, :Dl]
         if key.endswith("mlp.fc2.weight"):
-            return t[:, :F]
-        return t
+            return t[:Dl, :F]
+        if not self.padded:
+            return t
+        if t.dim() == 1:
+            return t[:Dl]
+        if key.endswith("qkv.weight"):
+            return t.view(3, H, HDP, self.D)[:, :, :HD, :Dl]
+        if key.endswith("cross_attn.kv.weight"):
+            return t.view(2, H, HDP, self.D)[:, :, :HD, :Dl]
+        if key.endswith("cross_attn.q.weight"):
+            return t.view(H, HDP, self.D)[:, :HD, :Dl]
+        if key.endswith("proj.weight"):                       # attn.proj / self_attn.proj / cross_attn.proj: [D, A]
+            return t.view(self.D, H, HDP)[:Dl, :, :HD]
+        if key == "decoder_proj_context.weight":
+            return t[:Dl, :Dl]
+        return t[:, :Dl]                                      # token tables, to_logits: [V, D]
+
+    def _ref_shape(self, key: str) -> Tuple[int, ...]:
+        """shape of the reference's tensor `key`"""
+        v = self._view_for_key(key)
+        if v.dim() == 4:
+            return (v.shape[0] * v.shape[1] * v.shape[2], v.shape[3])
+        if v.dim() == 3 and key.endswith("cross_attn.q.weight"):
+            return (v.shape[0] * v.shape[1], v.shape[2])
+        if v.dim() == 3:
+            return (v.shape[0], v.shape[1] * v.shape[2])
+        return tuple(v.shape)
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> List[str]:
         """Copies every known entry into the flat buffer; returns the keys this engine has no storage for (the module's
@@ -244,29 +296,33 @@ class Engine:
                 unexpected.append(key)
                 continue
             v = self._view_for_key(key)
-            v.copy_(val.to(self.dev, F32).reshape(v.shape))
+            v.copy_(val.to(self.dev, F32).reshape(v.shape))        # (padded layouts: v is a strided view without the pads)
         self.weights_dirty = True
         return unexpected
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}
-        cfg, D = self.cfg, self.D
+        cfg, D = self.cfg, self.Dl
+
+        def ref(name):           # the reference's tensor: a view of the storage, or (padded layouts) a copy without the pads
+            return self._view_for_key(name).reshape(self._ref_shape(name))
+
         for m in self.mods:
             e, d = f"encoder_embeddings.{m.name}", f"decoder_embeddings.{m.name}"
-            out[f"{e}.mod_emb"] = self.p[f"{e}.mod_emb"].view(1, 1, D)
-            out[f"{e}.token_emb.weight"] = self.p[f"{e}.token_emb.weight"]
-            out[f"{e}.pos_emb"] = self.pos[m.name][None]
+            out[f"{e}.mod_emb"] = ref(f"{e}.mod_emb").view(1, 1, D)
+            out[f"{e}.token_emb.weight"] = ref(f"{e}.token_emb.weight")
+            out[f"{e}.pos_emb"] = self.pos[m.name][None, :, :D]
             out[f"{d}.mod_emb"] = out[f"{e}.mod_emb"]
-            out[f"{d}.token_emb.weight"] = self.p[f"{d}.token_emb.weight"]
-            out[f"{d}.to_logits.weight"] = self.p[self.logit_key[m.name]]
-            out[f"{d}.pos_emb"] = self.pos[m.name][None]
+            out[f"{d}.token_emb.weight"] = ref(f"{d}.token_emb.weight")
+            out[f"{d}.to_logits.weight"] = ref(self.logit_key[m.name])
+            out[f"{d}.pos_emb"] = self.pos[m.name][None, :, :D]
         zeros = torch.zeros(D, device=self.dev)
         for name in self.p:
             if name.startswith(("encoder.", "decoder.", "encoder_norm", "decoder_norm", "decoder_proj_context")):
-                out[name] = self._view_for_key(name)
+                out[name] = ref(name)
                 if name.endswith("norm.weight") or ".norm" in name or "norm1" in name or "norm2" in name:
                     out[name[:-len("weight")] + "bias"] = zeros
-        out["mask_token"] = self.p["mask_token"].view(1, 1, D)
+        out["mask_token"] = ref("mask_token").view(1, 1, D)
         return out
 
     def _canon_key(self, key: str) -> str:
@@ -278,14 +334,8 @@ class Engine:
         return key
 
     def grad_of(self, key: str) -> torch.Tensor:
-        F = self.F
         key = self._canon_key(key)
-        t = self.g[key]
-        if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
-            return t[:F]
-        if key.endswith("mlp.fc2.weight"):
-            return t[:, :F]
-        return t
+        return self._logical(key, self.g[key]).reshape(self._ref_shape(key))
 
     @torch.no_grad()
     def init_random(self, seed: int = 0):
@@ -310,7 +360,7 @@ class Engine:
             elif name.endswith(".bias"):
                 v.zero_()
             else:
-                fo, fi = v.shape
+                fo, fi = self._ref_shape(name)
                 if "qkv" in name: fo //= 3
                 elif "kv" in name: fo //= 2
                 a = math.sqrt(6.0 / (fo + fi))
@@ -337,7 +387,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ workspaces
     def _alloc_workspaces(self):
-        B, N, M, D, Fp, H = self.Bmax, self.N, self.M, self.D, self.Fp, self.H
+        B, N, M, D, A, Fp, H = self.Bmax, self.N, self.M, self.D, self.A, self.Fp, self.H
         dev, cfg = self.dev, self.cfg
         RN, RM = B * N, B * M
 
@@ -360,17 +410,17 @@ class Engine:
         self.canon = e(self.n_mods, dt=I32)
 
         def enc_layer():
-            return dict(x=e(RN, D, dt=F32), xm=e(RN, D, dt=F32), ln1=e(RN, D), qkv=e(RN, 3 * D), ao=e(RN, D),
-                        ao_lo=e(RN, D) if self.attn_o_residual == "all" else None,
+            return dict(x=e(RN, D, dt=F32), xm=e(RN, D, dt=F32), ln1=e(RN, D), qkv=e(RN, 3 * A), ao=e(RN, A),
+                        ao_lo=e(RN, A) if self.attn_o_residual == "all" else None,
                         lse=e(B, H, N, dt=F32), st1=e(2, RN, dt=F32), ln2=e(RN, D), ab=e(RN, 2 * Fp), h=e(RN, Fp),
                         st2=e(2, RN, dt=F32))
 
         def dec_layer():
-            return dict(x=e(RM, D, dt=F32), x1=e(RM, D, dt=F32), x2=e(RM, D, dt=F32), ln1=e(RM, D), qkv=e(RM, 3 * D),
-                        ao=e(RM, D), ao_lo=e(RM, D) if self.attn_o_residual == "all" else None, lse=e(B, H, M, dt=F32),
-                        st1=e(2, RM, dt=F32), qn=e(RM, D), q=e(RM, D),
-                        stq=e(2, RM, dt=F32), cn=e(RN, D), kv=e(RN, 2 * D), stc=e(2, RN, dt=F32), xo=e(RM, D),
-                        xo_lo=e(RM, D) if self.attn_o_residual != "none" else None,
+            return dict(x=e(RM, D, dt=F32), x1=e(RM, D, dt=F32), x2=e(RM, D, dt=F32), ln1=e(RM, D), qkv=e(RM, 3 * A),
+                        ao=e(RM, A), ao_lo=e(RM, A) if self.attn_o_residual == "all" else None, lse=e(B, H, M, dt=F32),
+                        st1=e(2, RM, dt=F32), qn=e(RM, D), q=e(RM, A),
+                        stq=e(2, RM, dt=F32), cn=e(RN, D), kv=e(RN, 2 * A), stc=e(2, RN, dt=F32), xo=e(RM, A),
+                        xo_lo=e(RM, A) if self.attn_o_residual != "none" else None,
                         lse_x=e(B, H, M, dt=F32), ln2=e(RM, D), ab=e(RM, 2 * Fp), h=e(RM, Fp), st2=e(2, RM, dt=F32))
 
         self.enc = [enc_layer() for _ in range(cfg.encoder_depth)]
@@ -400,8 +450,10 @@ class Engine:
         self.dxe_b = e(RN, D)
         self.t_d = e(R, D)                         # generic [rows, D] bf16 temp
         self.t_d2 = e(R, D)
-        self.t_3d = e(R, 3 * D)
-        self.t_2d = e(RN, 2 * D)
+        # [rows, A] temps (gradients of attention outputs / queries): the same memory as t_d / t_d2 when A == D
+        self.t_a, self.t_a2 = (self.t_d, self.t_d2) if A == D else (e(R, A), e(R, A))
+        self.t_3d = e(R, 3 * A)
+        self.t_2d = e(RN, 2 * A)
         self.t_f = e(R, Fp)
         self.t_2f = e(R, 2 * Fp)
         self.dyn = torch.zeros(RM, D, device=dev, dtype=BF16)
@@ -422,7 +474,7 @@ class Engine:
             ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], eps=self.cfg.eps, q8=q, qscale=self.qs)
             self._q_of = (y.data_ptr(), rows, self.D)
         else:
-            ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], out_row=out_row, eps=self.cfg.eps)
+            ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], out_row=out_row, eps=self.cfg.eps, width=self.Dl)
 
     def _qbuf(self, rows, K):
         if getattr(self, "q8", None) is None or self.q8.shape[0] < rows:
@@ -486,19 +538,19 @@ class Engine:
                 run()
 
     def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk, o_lo=None):
-        D = self.D
+        A = self.A
         ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
-                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, lse, ks, ke, r_bs, r_rs,
-                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr())
+                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, lse, ks, ke, r_bs, r_rs,
+                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP)
 
     def _attn_bwd(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, do_t, lse, dq_t, dkv_t, ks, ke, r_bs, r_rs, B, Nq, Nk,
                   o_lo=None):
-        D = self.D
+        A = self.A
         ops.attn_bwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
-                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * D, D, do_t.data_ptr(), Nq * D, D,
+                     kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, do_t.data_ptr(), Nq * A, A,
                      lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
                      kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale,
-                     o_lo=None if o_lo is None else o_lo.data_ptr())
+                     o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP)
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
@@ -511,7 +563,7 @@ class Engine:
         64-clip micro-batch are read once instead of twice); `backward` must then be given the same value."""
         if self.weights_dirty:
             self.refresh_weights()
-        cfg, D, Fp, N, M = self.cfg, self.D, self.Fp, self.N, self.M
+        cfg, D, A, Fp, N, M = self.cfg, self.D, self.A, self.Fp, self.N, self.M
         mods = self.mods
         B = mod_dict[mods[0].name]["input_mask"].shape[0]
         if B > self.Bmax:
@@ -556,7 +608,7 @@ class Engine:
             self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln1"], w["qkv"], RN)
             # key-padding mask = one interval [0, n_valid) per SAMPLE (the per-row copies ce["ks"/"ke"] hold the same
             # numbers): the uniform form lets the attention kernels walk one (batch, head) pair per XCD (L2-resident K / V)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N,
+            self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], self.zero_b, ce["n_valid"], 1, 0, B, N, N,
                        o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], w["xm"], RN, L.EPI_RESID, R=w["x"])
             self._ln(w["xm"][:RN], f"{pre}.norm2.weight", w["ln2"], w["st2"])
@@ -573,14 +625,14 @@ class Engine:
             nxt = self.dec[i + 1]["x"] if i + 1 < cfg.decoder_depth else self.y_out
             self._ln(w["x"][:RM], f"{pre}.norm1.weight", w["ln1"], w["st1"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln1"], w["qkv"], RM)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M,
+            self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M,
                        o_lo=w["ao_lo"])
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
             self._ln(w["x1"][:RM], f"{pre}.query_norm.weight", w["qn"], w["stq"])
             self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
             self._ln(self.ctx[:RN], f"{pre}.context_norm.weight", w["cn"], w["stc"])
             self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
-            self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N,
+            self._attn(w["q"], 0, A, w["kv"], 0, A, 2 * A, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N,
                        o_lo=w["xo_lo"])
             self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["xo"], w["x2"], RM, L.EPI_RESID, R=w["x1"])
             self._ln(w["x2"][:RM], f"{pre}.norm2.weight", w["ln2"], w["st2"])
@@ -588,7 +640,7 @@ class Engine:
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], nxt, RM, L.EPI_RESID, R=w["x2"])
         # decoder_norm, rows written modality-grouped (the row order of y[decoder_mod_mask == id], :633)
         ops.layernorm_fwd(self.y_out[:RM], self.p["decoder_norm.weight"], self.yn, self.st_dn[0], self.st_dn[1],
-                          out_row=self.perm if group_rows else None, eps=cfg.eps)
+                          out_row=self.perm if group_rows else None, eps=cfg.eps, width=self.Dl)
         self._have_fwd = True
         if not need_loss:
             return None
@@ -628,20 +680,20 @@ class Engine:
         self._lin_bwd(f"{pre}.mlp.fc13", dab, w["ln2"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],
-                          dx_in=dres, dx_bf16=nb)
+                          dx_in=dres, dx_bf16=nb, width=self.Dl)
         return nb
 
     def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke, r_bs=None, r_rs=1):
-        D, B = self.D, self.B
+        A, B = self.A, self.B
         r_bs = Nq if r_bs is None else r_bs
-        dao, dqkv, dln = self.t_d, self.t_3d, self.t_d2
+        dao, dqkv, dln = self.t_a, self.t_3d, self.t_d2
         self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
-        self._attn_bwd(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq,
+        self._attn_bwd(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq,
                        o_lo=w["ao_lo"])
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
-                          dx_in=dres, dx_bf16=nb)
+                          dx_in=dres, dx_bf16=nb, width=self.Dl)
         return nb
 
     def _set_gscale(self, gscale):
@@ -655,7 +707,7 @@ class Engine:
         `gscale` (float or 1-element device tensor: the upstream d loss).  `bucket_done(name, lo, hi)` is
         called (in launch order) as soon as every kernel writing G[lo:hi] has been enqueued."""
         assert self._have_fwd, "backward() needs a forward()"
-        cfg, D, N, M, B = self.cfg, self.D, self.N, self.M, self.B
+        cfg, D, A, N, M, B = self.cfg, self.D, self.A, self.N, self.M, self.B
         RN, RM = B * N, B * M
         mods, ce, cd = self.mods, self.ce, self.cd
         if getattr(self, "_ce_done", None):
@@ -688,7 +740,7 @@ class Engine:
             done(f"dec_table.{m.name}" if cfg.share_embedding else f"to_logits.{m.name}")
         dres, dres_b = self.dres, self._ring_next()
         ops.layernorm_bwd(self.dyn, self.y_out[:RM], self.st_dn[0], self.st_dn[1], self.p["decoder_norm.weight"], dres,
-                          self.g["decoder_norm.weight"], dx_in=None, dx_bf16=dres_b, dy_row=self.perm)
+                          self.g["decoder_norm.weight"], dx_in=None, dx_bf16=dres_b, dy_row=self.perm, width=self.Dl)
 
         # ---- decoder layers
         first_ctx = True
@@ -696,19 +748,19 @@ class Engine:
             w, pre = self.dec[i], f"decoder.{i}"
             dres_b = self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
             # cross attention
-            dxo, dq, dkv, dln = self.t_d, self.t_d2, self.t_2d, self.t_d
+            dxo, dq, dkv, dln = self.t_a, self.t_a2, self.t_2d, self.t_d
             self._lin_bwd(f"{pre}.cross_attn.proj.weight", dres_b, w["xo"], dxo, RM)
-            self._attn_bwd(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["xo"], dxo, w["lse_x"], dq, dkv, self.zero_b, ce["n_valid"],
+            self._attn_bwd(w["q"], 0, A, w["kv"], 0, A, 2 * A, w["xo"], dxo, w["lse_x"], dq, dkv, self.zero_b, ce["n_valid"],
                            1, 0, B, M, N, o_lo=w["xo_lo"])
             self._lin_bwd(f"{pre}.cross_attn.q.weight", dq, w["qn"], dln, RM)
             nb = self._ring_next()
             ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
-                              self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=nb)
+                              self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=nb, width=self.Dl)
             dres_b = nb
             dcn = self.t_d3            # not t_d2: dq is still being read by the q-projection wgrad on the side stream
             self._lin_bwd(f"{pre}.cross_attn.kv.weight", dkv, w["cn"], dcn, RN)
             ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
-                              self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx)
+                              self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
             first_ctx = False
             dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"])
             done(pre)
@@ -727,7 +779,7 @@ class Engine:
         self._lin_bwd("decoder_proj_context.weight", self.dctx_b, self.xe, dxe_n, RN)
         dxe, dxe_b = self.dxe, self._ring_next()
         ops.layernorm_bwd(dxe_n, self.x_enc_out[:RN], self.st_en[0], self.st_en[1], self.p["encoder_norm.weight"], dxe,
-                          self.g["encoder_norm.weight"], dx_in=None, dx_bf16=dxe_b)
+                          self.g["encoder_norm.weight"], dx_in=None, dx_bf16=dxe_b, width=self.Dl)
         done("bridge")
 
         # ---- encoder layers
@@ -782,7 +834,7 @@ class Engine:
         key = (B, Nmax, Mmax)
         if not fresh and self._infer_key is not None and all(a >= b for a, b in zip(self._infer_key, key)):
             return self._iw
-        D, Fp, H, dev = self.D, self.Fp, self.H, self.dev
+        D, A, Fp, H, dev = self.D, self.A, self.Fp, self.H, self.dev
         R = B * max(Nmax, Mmax)
 
         def e(*shape, dt=BF16):
@@ -795,8 +847,8 @@ class Engine:
                       err=torch.zeros(1, device=dev, dtype=I32)),
             xa=e(R, D, dt=F32), xb=e(R, D, dt=F32), emb=e(B * Nmax, D, dt=F32), ctx=e(B * Nmax, D, dt=F32),
             ya=e(B * Mmax, D, dt=F32), yb=e(B * Mmax, D, dt=F32),
-            ln=e(R, D), qkv=e(R, 3 * D), ao=e(R, D), ab=e(R, 2 * Fp), h=e(R, Fp), q=e(B * Mmax, D), cn=e(B * Nmax, D),
-            kv=e(B * Nmax, 2 * D), st=e(2, R, dt=F32), lse=e(B, H, max(Nmax, Mmax), dt=F32),
+            ln=e(R, D), qkv=e(R, 3 * A), ao=e(R, A), ab=e(R, 2 * Fp), h=e(R, Fp), q=e(B * Mmax, A), cn=e(B * Nmax, D),
+            kv=e(B * Nmax, 2 * A), st=e(2, R, dt=F32), lse=e(B, H, max(Nmax, Mmax), dt=F32),
             zero_b=torch.zeros(B, device=dev, dtype=I32), full_m=torch.zeros(B, device=dev, dtype=I32),
             dslot=torch.zeros(B * Mmax, device=dev, dtype=I32), dtok=torch.zeros(B * Mmax, device=dev, dtype=I32),
         )
@@ -815,7 +867,7 @@ class Engine:
         ROAR order; decoder self-attention is unmasked, sa_mask=None at :761).  Returns bf16 logits [B, M, V]."""
         if self.weights_dirty:
             self.refresh_weights()
-        cfg, D, Fp, H = self.cfg, self.D, self.Fp, self.H
+        cfg, D, A, Fp, H = self.cfg, self.D, self.A, self.Fp, self.H
         byname = {m.name: m for m in self.mods}
         mods = [m for m in self.mods if m.name in enc_inputs]
         tm = byname[target]
@@ -836,7 +888,7 @@ class Engine:
                 pre = f"encoder.{i}"
                 self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
-                self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
+                self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
                 self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
                 self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
                 self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
@@ -854,14 +906,14 @@ class Engine:
             pre = f"decoder.{i}"
             self._ln(y[:RM], f"{pre}.norm1.weight", w["ln"], w["st"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RM)
-            self._attn(w["qkv"], 0, 3 * D, w["qkv"], D, 2 * D, 3 * D, w["ao"], w["lse"], w["zero_b"], w["full_m"], 1, 0, B, M, M)
+            self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], w["zero_b"], w["full_m"], 1, 0, B, M, M)
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RM, L.EPI_RESID, R=y)
             if N > 0:
                 self._ln(yn[:RM], f"{pre}.query_norm.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RM)
                 self._ln(w["ctx"][:RN], f"{pre}.context_norm.weight", w["cn"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
-                self._attn(w["q"], 0, D, w["kv"], 0, D, 2 * D, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, M, N)
+                self._attn(w["q"], 0, A, w["kv"], 0, A, 2 * A, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, M, N)
                 self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RM, L.EPI_RESID, R=yn)
             else:
                 # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the

@@ -29,10 +29,12 @@ def _need_cuda(*ts):
 
 
 # ------------------------------------------------------------------------------------------
-def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None):
+def layernorm_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None, width=None):
+    """width: the normalised width when the rows are stored padded (x.shape[1] is the pitch; pad columns of x are zero)"""
     _need_cuda(x)
-    rows, D = x.shape
-    check(L.load().ego_layernorm_fwd(_p(x), _p(w), _p(y), _p(mean), _p(rstd), _p(out_row), rows, D, eps, _p(q8),
+    rows, ld = x.shape
+    D = ld if width is None else width
+    check(L.load().ego_layernorm_fwd(_p(x), _p(w), _p(y), _p(mean), _p(rstd), _p(out_row), rows, D, ld, eps, _p(q8),
                                      0 if q8 is None else q8.stride(-2), _p(qscale), _stream()), "ego_layernorm_fwd")
 
 
@@ -48,13 +50,14 @@ def _work(device, n_floats):
     return buf
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None, width=None):
     _need_cuda(x)
-    rows, D = x.shape
+    rows, ld = x.shape
+    D = ld if width is None else width
     lib = L.load()
     wk = _work(x.device, lib.ego_layernorm_bwd_work_floats(rows, D))
     check(lib.ego_layernorm_bwd(_p(dy), _p(dy_row), _p(x), _p(mean), _p(rstd), _p(w), _p(dx_in), _p(dx_out),
-                                _p(dx_bf16), _p(dw), _p(wk), wk.numel(), rows, D, _stream()), "ego_layernorm_bwd")
+                                _p(dx_bf16), _p(dw), _p(wk), wk.numel(), rows, D, ld, _stream()), "ego_layernorm_bwd")
 
 
 def gemm_nt(A, B, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None, m_range=None, lda=None, ldb=None, ldc=None, ldr=None):
@@ -139,14 +142,25 @@ def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
     return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))
 
 
-def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None):
-    """o_lo (optional device pointer, laid out like o): receives the bf16 rounding residual of the output"""
+def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None,
+             hd_pad=64):
+    """o_lo (optional device pointer, laid out like o): receives the bf16 rounding residual of the output.
+    hd_pad: elements per stored head (64: the throughput kernels; 96 / 128: zero-padded heads of another dimension)"""
+    if hd_pad != 64:
+        check(L.load().ego_attn_fwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
+                                       r_bs, r_rs, B, H, Nq, Nk, hd_pad, scale, _stream()), "ego_attn_fwd_hd")
+        return
     check(L.load().ego_attn_fwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
                                     r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_fwd_d64")
 
 
 def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
-             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None):
+             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None, hd_pad=64):
+    if hd_pad != 64:
+        check(L.load().ego_attn_bwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
+                                       _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
+                                       _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, hd_pad, scale, _stream()), "ego_attn_bwd_hd")
+        return
     check(L.load().ego_attn_bwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                     _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
                                     _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_bwd_d64")

@@ -85,24 +85,25 @@ class KernelTimer:
                 n = (ke[:B].clamp(max=Nk) - ks[:B]).clamp(min=0).double().sum().item()
             return n
 
-        def c_attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, Hh, Nq, Nk, scale, o_lo=None):
+        def c_attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, Hh, Nq, Nk, scale, o_lo=None,
+                       hd_pad=64):
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
-            return 4.0 * 64 * Hh * p, 2.0 * B * Hh * 64 * ((3 if o_lo is not None else 2) * Nq + 2 * Nk)
+            return 4.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((3 if o_lo is not None else 2) * Nq + 2 * Nk)
 
-        def c_attn_bwd(*a, o_lo=None):
+        def c_attn_bwd(*a, o_lo=None, hd_pad=64):
             ks, ke, r_bs, r_rs, B, Hh, Nq, Nk = a[-9], a[-8], a[-7], a[-6], a[-5], a[-4], a[-3], a[-2]
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
-            return 10.0 * 64 * Hh * p, 2.0 * B * Hh * 64 * ((5 if o_lo is not None else 4) * Nq + 4 * Nk)
+            return 10.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((5 if o_lo is not None else 4) * Nq + 4 * Nk)
 
         def rowcost(bytes_per_row_elem):
             def c(*a, **k):
                 return 0.0, 0.0
             return c
 
-        def c_ln_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None):
+        def c_ln_fwd(x, w, y, mean, rstd, out_row=None, eps=1e-6, q8=None, qscale=None, width=None):
             return 0.0, x.shape[0] * x.shape[1] * (7.0 if q8 is not None else 6.0)
 
-        def c_ln_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None):
+        def c_ln_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy_row=None, width=None):
             n = x.shape[0] * x.shape[1]
             return 0.0, n * (2.0 + 4.0 + 4.0 + (4.0 if dx_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0))
 

@@ -23,8 +23,9 @@ extern "C" {
 
 /* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
  * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; 3: round 3 gave ego_layernorm_bwd,
- * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; loaders must refuse other versions) */
-#define EGO_ABI_VERSION 3
+ * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; 4: ego_layernorm_fwd / _bwd take the
+ * row pitch `ld` beside the normalised width D; loaders must refuse other versions) */
+#define EGO_ABI_VERSION 4
 #define EGO_MAX_MODS 8
 
 /* GEMM epilogues */
@@ -115,16 +116,19 @@ int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* 
 
 /* Bias-free LayerNorm (egom2p/models/egom2p_utils.py:118-133): y(bf16)[out_row[r]] = LN(x[r]) * w.
  * out_row may be NULL (identity); -1 drops the row. mean/rstd are saved for the backward.  q8 / qscale (optional): the
- * row also leaves as e4m3 bytes + scale, exactly what ego_quant_fp8_rows would make of y (operand of an fp8 GEMM). */
+ * row also leaves as e4m3 bytes + scale, exactly what ego_quant_fp8_rows would make of y (operand of an fp8 GEMM; ld == D).
+ * D = the normalised width, ld >= D = the row pitch of x and y in elements (ld > D: a model dimension stored padded - the
+ * registered ego-L's 1020 in rows of 1024; the columns [D, ld) of x must be zero, those of y are written as zeros). */
 int ego_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* mean, float* rstd, const int* out_row,
-                      int rows, int D, float eps, void* q8, long ldq, float* qscale, hipStream_t stream);
+                      int rows, int D, long ld, float eps, void* q8, long ldq, float* qscale, hipStream_t stream);
 /* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row.  The weight gradient goes
  * through one partial row per workgroup in `work` (>= ego_layernorm_bwd_work_floats(rows, D) floats) and an ordered
- * reduction: no float atomics, bitwise reproducible. */
+ * reduction: no float atomics, bitwise reproducible.  D / ld as in the forward (dy, x, dx_* rows have pitch ld; the gradient's
+ * columns [D, ld) are written as zeros). */
 long ego_layernorm_bwd_work_floats(int rows, int D);
 int ego_layernorm_bwd(const void* dy_bf16, const int* dy_row, const float* x, const float* mean, const float* rstd,
                       const float* w, const float* dx_in, float* dx_out, void* dx_out_bf16, float* dw, float* work,
-                      long work_floats, int rows, int D, hipStream_t stream);
+                      long work_floats, int rows, int D, long ld, hipStream_t stream);
 
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 inputs, fp32 MFMA accumulate.  Replaces F.linear under
  * autocast(bf16) (egom2p_utils.py:141-169, 180-203, 215-242; decoder_embeddings.py:372-383, 489-500)
@@ -173,6 +177,19 @@ int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_
                      const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                      void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
                      int Nq, int Nk, float scale, hipStream_t stream);
+
+/* The same two entries for a head dimension other than 64: every head is stored padded with zero columns to
+ * hd_pad = 96 or 128 elements (the registered ego-L, egom2p_model.py:1080-1092, has 15 heads of 68: 68^-0.5 is `scale`),
+ * head h of a row at element offset h * hd_pad.  Parity kernels (LDS-staged tiles, every tile visited), not the
+ * throughput path.  LSE / DELTA are opaque to the caller, as above; other hd_pad -> EGO_ERR_ARG. */
+int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                    long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks, const int* ke,
+                    long r_bs, long r_rs, int B, int H, int Nq, int Nk, int hd_pad, float scale, hipStream_t stream);
+int ego_attn_bwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                    long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo, const void* dO, long do_bs, long do_rs,
+                    const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
+                    void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
+                    int Nq, int Nk, int hd_pad, float scale, hipStream_t stream);
 
 /* SwiGLU gate on the fused fc1||fc3 output ab[rows, 2F] (GatedMlp, egom2p_utils.py:167-169). */
 int ego_swiglu_fwd(const void* ab, void* h, long rows, int F, hipStream_t stream);

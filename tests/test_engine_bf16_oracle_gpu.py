@@ -33,7 +33,7 @@ LOSS_TOL = 3e-4
 # b12 = the registered full-depth ego-b (12e / 12d, 400 M parameters), L2 = ego-L width (D = 1152): three oracle passes of
 # one clip each (about a minute on the box's 16 host cores) - the full-size cases sit behind the tight bars too; L24 = the
 # full-depth ego-L of BASELINE config 5 (24e / 24d, D = 1152, 1.19 B parameters) at N = M = 1024
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b12", "L2", "L24"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b12", "L2", "L24", "L1020"])
 def test_engine_matches_bf16_mode_oracle(case):
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]
@@ -82,14 +82,15 @@ def test_engine_matches_bf16_mode_oracle(case):
     def act(name, got, ref, rows, extra=0.0):
         errs[name] = (rel_l2(got.float().cpu()[rows].numpy(), ref.detach()[rows].numpy()), ACT_TOL + extra)
 
+    Dp = eng.D                 # row pitch (> D for the registered ego-L: rows of 1024 for dim 1020, pad columns zero)
     blk0 = eng.enc[1]["x"] if cfg.encoder_depth > 1 else eng.x_enc_out
-    act("enc_block0", blk0[:RN].view(B, N, D), taps["enc_block0"], keep)
-    act("enc_out", eng.xe[:RN].view(B, N, D), taps["enc_out"], keep, extra=BF16_STORE)     # stored in bf16
-    act("context", eng.ctx[:RN].view(B, N, D), taps["context"], keep)
+    act("enc_block0", blk0[:RN].view(B, N, Dp)[..., :D], taps["enc_block0"], keep)
+    act("enc_out", eng.xe[:RN].view(B, N, Dp)[..., :D], taps["enc_out"], keep, extra=BF16_STORE)     # stored in bf16
+    act("context", eng.ctx[:RN].view(B, N, Dp)[..., :D], taps["context"], keep)
     dblk0 = eng.dec[1]["x"] if cfg.decoder_depth > 1 else eng.y_out
-    act("dec_block0", dblk0[:RM].view(B, M, D), taps["dec_block0"], dkeep)
+    act("dec_block0", dblk0[:RM].view(B, M, Dp)[..., :D], taps["dec_block0"], dkeep)
     perm = eng.perm[:RM].view(B, M).cpu()[dkeep].long()
-    errs["dec_out"] = (rel_l2(eng.yn[perm.cuda()].float().cpu().numpy(), taps["dec_out"].detach()[dkeep].numpy()),
+    errs["dec_out"] = (rel_l2(eng.yn[perm.cuda()][:, :D].float().cpu().numpy(), taps["dec_out"].detach()[dkeep].numpy()),
                        ACT_TOL + BF16_STORE)                       # stored in bf16
     print(case, {k: f"{v[0]:.2e}" for k, v in errs.items()})
     for k, (e, tol) in errs.items():

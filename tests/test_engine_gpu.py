@@ -44,10 +44,18 @@ def _tap(g, key, t):
     return max(e1, e2, e3)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24"])
+# L1020 = the REGISTERED ego-L geometry (dim 1020, 15 heads of 68, F = 2720: egom2p_model.py:1080-1092) at 2 + 2 layers: stored in rows
+# of 1024 with heads padded to 128 (engine.py) - the pad columns must stay exact zeros in activations and gradients
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim
+    Dp = eng.D                                           # row pitch of the engine's activations (== D unless stored padded)
+
+    def act(t, rows, n):
+        v = t[:rows].view(B, n, Dp)
+        assert Dp == D or not bool(v[..., D:].any()), "pad columns must be zero"
+        return v[..., :D]
     order = [str(x) for x in g["dec_order"]]
     loss, mod_loss = eng.forward(md, dec_order=order)
     torch.cuda.synchronize()
@@ -71,25 +79,25 @@ def test_engine_matches_reference(case):
 
     # ---- forward taps
     RN, RM = B * N, B * M
-    enc0 = eng.enc[0]["x"][:RN].view(B, N, D)
+    enc0 = act(eng.enc[0]["x"], RN, N)
     assert _tap(g, "enc_x0", enc0) < 1e-6                                     # exact fp32 gather + adds
-    assert _tap(g, "dec_y0", eng.dec[0]["x"][:RM].view(B, M, D)) < 1e-6
+    assert _tap(g, "dec_y0", act(eng.dec[0]["x"], RM, M)) < 1e-6
     blk0 = eng.enc[1]["x"] if cfg.encoder_depth > 1 else eng.x_enc_out
-    assert _tap(g, "enc_block0", blk0[:RN].view(B, N, D)) < ACT_TOL
-    assert _tap(g, "enc_out", eng.xe[:RN].view(B, N, D)) < ACT_TOL
-    assert _tap(g, "context", eng.ctx[:RN].view(B, N, D)) < ACT_TOL
+    assert _tap(g, "enc_block0", act(blk0, RN, N)) < ACT_TOL
+    assert _tap(g, "enc_out", act(eng.xe, RN, N)) < ACT_TOL
+    assert _tap(g, "context", act(eng.ctx, RN, N)) < ACT_TOL
     dblk0 = eng.dec[1]["x"] if cfg.decoder_depth > 1 else eng.y_out
     # pad rows of the decoder stream are never consumed by the reference (mod_mask -1): compare valid rows
     valid = torch.from_numpy(~g["dec_pad"]).cuda()
     if f"tap.dec_block0" in g.files:
         ref = torch.from_numpy(g["tap.dec_block0"]).cuda()
-        got = dblk0[:RM].view(B, M, D)
+        got = act(dblk0, RM, M)
         assert rel_l2(got[valid].cpu().numpy(), ref[valid].cpu().numpy()) < ACT_TOL
         refo = torch.from_numpy(g["tap.dec_out"]).cuda()[valid]
         perm = eng.perm[:RM].view(B, M)[valid].long()
-        assert rel_l2(eng.yn[perm].float().cpu().numpy(), refo.cpu().numpy()) < ACT_TOL
+        assert rel_l2(eng.yn[perm][:, :D].float().cpu().numpy(), refo.cpu().numpy()) < ACT_TOL
     else:
-        assert _tap(g, "dec_block0", dblk0[:RM].view(B, M, D)) < ACT_TOL     # canonical / ragged ego-b: heads are valid rows
+        assert _tap(g, "dec_block0", act(dblk0, RM, M)) < ACT_TOL            # canonical / ragged ego-b: heads are valid rows
 
     # ---- loss
     ref_loss = float(g["loss"])
@@ -116,7 +124,7 @@ def test_engine_matches_reference(case):
         assert int(src.min()) >= int(rng_h[c, 0]) and int(src.max()) < int(rng_h[c, 0]) + cnt
         l = eng.lin[eng.logit_key[m.name]]
         lg = torch.empty(rows, m.vocab_size, device="cuda", dtype=torch.bfloat16)
-        ops.gemm_nt(eng.yn[src].contiguous(), l.wb, lg, rows, m.vocab_size, D, 0, lda=D, ldb=D, ldc=m.vocab_size)
+        ops.gemm_nt(eng.yn[src].contiguous(), l.wb, lg, rows, m.vocab_size, Dp, 0, lda=Dp, ldb=Dp, ldc=m.vocab_size)
         lg = lg.float()
         assert rel_l2(lg[:ref_head.shape[0], :16].cpu().numpy(), ref_head) < 3e-2, m.name
         ref_am_t = torch.from_numpy(ref_am.astype(np.int64)).cuda()
@@ -161,6 +169,13 @@ def test_engine_matches_reference(case):
             e = rel_l2(gr.reshape(-1, gr.shape[-1])[:4, :32].float().cpu().numpy(), g[key])
             assert e < 2 * GRAD_TOL, (n, e)
 
+    if eng.padded:             # every gradient element outside the reference's tensors (pad columns / pad head rows) is an exact zero
+        rest = eng.G.clone()
+        for n, (o, cnt, shape) in eng.offsets.items():
+            eng._logical(n, rest[o:o + cnt].view(shape)).zero_()
+        assert not bool(rest.any())
+        del rest
+
     # optimiser: flat-buffer clip + AdamW (reference: clip_grad_norm_(1.0) then AdamW lr 1e-3, wd 0.05 / 0)
     sqn = torch.zeros(1, device="cuda", dtype=torch.float64)
     ops.grad_sqnorm(eng.G, sqn)
@@ -171,6 +186,12 @@ def test_engine_matches_reference(case):
         ops.adamw_step(eng.P[lo:hi], eng.G[lo:hi], m_buf[lo:hi], v_buf[lo:hi], meta["lr"], 0.0 if nd else meta["wd"], 1,
                        gscale=1.0, max_norm=1.0, sqnorm=sqn)
     torch.cuda.synchronize()
+    if eng.padded:             # ... and AdamW leaves the pads of the parameters at zero
+        rest = eng.P.clone()
+        for n, (o, cnt, shape) in eng.offsets.items():
+            eng._logical(n, rest[o:o + cnt].view(shape)).zero_()
+        assert not bool(rest.any())
+        del rest
     new = eng.state_dict()
     for key in g.files:
         if key.startswith("adamw.") or key.startswith("adamw_head."):

@@ -331,6 +331,74 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
     assert _rel(gv, v.grad) < 2e-2, ("dv", _rel(gv, v.grad))
 
 
+@pytest.mark.parametrize("hd,hdp", [(68, 96), (68, 128), (96, 96), (120, 128)])
+@pytest.mark.parametrize("B,H,Nq,Nk,kind", [(2, 3, 200, 333, "ragged"), (1, 5, 1100, 1100, "blocks"), (2, 2, 30, 30, "pad"),
+                                             (1, 2, 256, 512, "full"), (3, 2, 100, 160, "sample")])
+def test_attention_other_head_dims(hd, hdp, B, H, Nq, Nk, kind):
+    """ego_attn_*_hd: heads of dimension hd stored zero-padded to hdp (the registered ego-L has 15 heads of 68) against fp32
+    torch on the UNPADDED heads; the gradient's pad columns must come out exactly zero (they are the pad rows' weights' only
+    source of gradient)."""
+    A = H * hdp
+    def padded(*shape):
+        t = torch.zeros(*shape, H, hdp, device=DEV)
+        t[..., :hd] = torch.randn(*shape, H, hd, device=DEV)
+        return _bf(t)
+    qb = padded(B, Nq).view(B, Nq, A)
+    kvb = padded(B, Nk, 2).view(B, Nk, 2, A)
+    ks = torch.zeros(B, Nq, dtype=torch.int32, device=DEV)
+    ke = torch.full((B, Nq), Nk, dtype=torch.int32, device=DEV)
+    r_bs, r_rs = Nq, 1
+    if kind == "ragged":
+        ks = torch.randint(0, Nk // 2, (B, Nq), device=DEV, dtype=torch.int32)
+        ke = ks + torch.randint(0, Nk // 2, (B, Nq), device=DEV, dtype=torch.int32)
+        ke[:, 5] = ks[:, 5]
+    elif kind == "blocks":
+        bounds = [0, 500, 530, 1070, 1100]
+        for a, b_ in zip(bounds[:-1], bounds[1:]):
+            ks[:, a:b_] = a
+            ke[:, a:b_] = b_
+    elif kind == "pad":
+        ke[:] = 17
+    elif kind == "sample":
+        nv = torch.tensor([160, 77, 1], dtype=torch.int32, device=DEV)
+        ke = nv[:, None].expand(B, Nq).contiguous()
+    scale = hd ** -0.5
+    q = qb.view(B, Nq, H, hdp)[..., :hd].permute(0, 2, 1, 3).float().requires_grad_(True)
+    k = kvb[:, :, 0].reshape(B, Nk, H, hdp)[..., :hd].permute(0, 2, 1, 3).float().requires_grad_(True)
+    v = kvb[:, :, 1].reshape(B, Nk, H, hdp)[..., :hd].permute(0, 2, 1, 3).float().requires_grad_(True)
+    ref = _attn_ref(q, k, v, ks.long(), ke.long(), scale)
+    if kind == "sample":                     # one interval per sample: row stride 0
+        ks_k, ke_k, r_bs, r_rs = torch.zeros(B, dtype=torch.int32, device=DEV), nv, 1, 0
+    else:
+        ks_k, ke_k = ks, ke
+    o = torch.empty(B, Nq, A, device=DEV, dtype=torch.bfloat16)
+    o_lo = torch.empty_like(o)
+    lse = torch.empty(B, H, Nq, device=DEV)
+    kp, vp = kvb.data_ptr(), kvb.data_ptr() + A * 2
+    ops.attn_fwd(qb.data_ptr(), Nq * A, A, kp, Nk * 2 * A, 2 * A, vp, Nk * 2 * A, 2 * A, o.data_ptr(), Nq * A, A, lse, ks_k, ke_k,
+                 r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=o_lo.data_ptr(), hd_pad=hdp)
+    got = o.view(B, Nq, H, hdp).float()
+    assert (got[..., hd:] == 0).all()
+    assert _rel(got[..., :hd].permute(0, 2, 1, 3), ref) < 1e-2
+    full = (o.float() + o_lo.float()).view(B, Nq, H, hdp)[..., :hd].permute(0, 2, 1, 3)
+    assert _rel(full, ref) < _rel(got[..., :hd].permute(0, 2, 1, 3), ref)        # the residual adds bits (the rest is P's own bf16 rounding)
+
+    do = padded(B, Nq).view(B, Nq, A)
+    ref.backward(do.view(B, Nq, H, hdp)[..., :hd].permute(0, 2, 1, 3).float())
+    dq = torch.full((B, Nq, A), 7.0, device=DEV, dtype=torch.bfloat16)
+    dkv = torch.full((B, Nk, 2, A), 7.0, device=DEV, dtype=torch.bfloat16)
+    delta = torch.empty(B, H, Nq, device=DEV)
+    ops.attn_bwd(qb.data_ptr(), Nq * A, A, kp, Nk * 2 * A, 2 * A, vp, Nk * 2 * A, 2 * A, o.data_ptr(), Nq * A, A,
+                 do.data_ptr(), Nq * A, A, lse, delta, dq.data_ptr(), Nq * A, A, dkv.data_ptr(), Nk * 2 * A, 2 * A,
+                 dkv.data_ptr() + A * 2, Nk * 2 * A, 2 * A, ks_k, ke_k, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=o_lo.data_ptr(), hd_pad=hdp)
+    gq = dq.view(B, Nq, H, hdp).float()
+    gk = dkv[:, :, 0].reshape(B, Nk, H, hdp).float()
+    gv = dkv[:, :, 1].reshape(B, Nk, H, hdp).float()
+    for nm, g_, r_ in (("dq", gq, q.grad), ("dk", gk, k.grad), ("dv", gv, v.grad)):
+        assert (g_[..., hd:] == 0).all(), nm
+        assert _rel(g_[..., :hd].permute(0, 2, 1, 3), r_) < 2e-2, (nm, _rel(g_[..., :hd].permute(0, 2, 1, 3), r_))
+
+
 def test_attention_per_sample_interval():
     B, H, Nq, Nk = 3, 2, 100, 160
     D = H * 64
@@ -428,6 +496,32 @@ def test_cross_entropy():
     ops.ce_bwd(logits, V, V, tgt, rng, 260, lse, g, 2)
     assert _rel(logits[40:240].float(), lf.grad) < 5e-3
     assert torch.equal(logits[:40], keep[:40]) and torch.equal(logits[240:], keep[240:])
+
+
+def test_layernorm_on_padded_rows():
+    """LayerNorm over D = 1020 columns stored in rows of 1024 (the registered ego-L): statistics over the 1020, pad columns
+    of the output and of the input gradient written as zeros, weight gradient of the 1020 only."""
+    rows, D, ld = 777, 1020, 1024
+    x = torch.zeros(rows, ld, device=DEV); x[:, :D] = torch.randn(rows, D, device=DEV) * 2 + 0.3
+    w = torch.zeros(ld, device=DEV); w[:D] = torch.rand(D, device=DEV) + 0.5
+    y = torch.full((rows, ld), 9.0, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, w, y, mean, rstd, eps=1e-6, width=D)
+    xr = x[:, :D].clone().requires_grad_(True)
+    wr = w[:D].clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, None, 1e-6)
+    assert _rel(y[:, :D].float(), ref) < 4e-3 and not bool(y[:, D:].any())
+    assert _rel(mean, xr.mean(-1)) < 1e-5
+    dy = torch.zeros(rows, ld, device=DEV); dy[:, :D] = torch.randn(rows, D, device=DEV)
+    dy = _bf(dy)
+    ref.backward(dy[:, :D].float())
+    dx_in = torch.zeros(rows, ld, device=DEV); dx_in[:, :D] = torch.randn(rows, D, device=DEV)
+    dx = torch.full((rows, ld), 9.0, device=DEV)
+    dxb = torch.full((rows, ld), 9.0, device=DEV, dtype=torch.bfloat16)
+    dw = torch.zeros(ld, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, w, dx, dw, dx_in=dx_in, dx_bf16=dxb, width=D)
+    assert _rel(dx[:, :D], xr.grad + dx_in[:, :D]) < 1e-4 and not bool(dx[:, D:].any()) and not bool(dxb[:, D:].any())
+    assert _rel(dw[:D], wr.grad) < 1e-4 and not bool(dw[D:].any())
 
 
 @pytest.mark.parametrize("V", [64000, 256, 65536, 2056])
