@@ -333,6 +333,22 @@ class Engine:
             key = key.replace("to_logits.weight", "token_emb.weight")
         return key
 
+    def param_views(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(parameter, gradient) of the reference's tensor `key` as VIEWS of the flat buffers - what the nn.Module wrapper
+        registers as nn.Parameter / .grad.  They have the reference's shape (mod_emb / mask_token: (1, 1, dim)) except, on a
+        padded layout, the attention weights: there a head's rows are not contiguous with the next head's, so the views keep
+        the head axis ((3, H, hd, dim) for qkv, (2, H, hd, dim) for kv, (H, hd, dim) for q, (dim, H, hd) for proj); element
+        order = the reference's (`.reshape(reference shape)` gives its tensor)."""
+        ck = self._canon_key(key)
+        out = []
+        for store in (self.p, self.g):
+            v = self._logical(ck, store[ck])
+            if v.dim() <= 2:
+                shape = (1, 1, self.Dl) if (ck.endswith("mod_emb") or ck == "mask_token") else self._ref_shape(ck)
+                v = v.view(shape)
+            out.append(v)
+        return out[0], out[1]
+
     def grad_of(self, key: str) -> torch.Tensor:
         key = self._canon_key(key)
         return self._logical(key, self.g[key]).reshape(self._ref_shape(key))

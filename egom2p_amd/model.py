@@ -226,7 +226,7 @@ class EgoM2P(nn.Module):
             if key.endswith("pos_emb") or (key.endswith(".bias") and "norm" in key):
                 attach(self, key, val if key.endswith("pos_emb") else zeros, buffer=True)
                 continue
-            g = eng.grad_of(key).view(val.shape)
+            val, g = eng.param_views(key)                  # views of the flat buffers (see Engine.param_views for their shapes)
             ident = (val.data_ptr(), tuple(val.shape))
             if ident in shared:                      # tied tensors share ONE Parameter (mod_emb, to_logits)
                 parts = key.split(".")
@@ -270,8 +270,8 @@ class EgoM2P(nn.Module):
                     p.fill_(1.0)
                 elif name.endswith(".bias"):
                     p.zero_()
-                elif p.dim() == 2:
-                    fan_out, fan_in = p.shape
+                elif p.dim() >= 2:
+                    fan_out, fan_in = self.engine._ref_shape(self.engine._canon_key(name))     # (a padded layout exposes per-head views)
                     if "qkv" in name: fan_out //= 3
                     elif "kv" in name: fan_out //= 2
                     a = math.sqrt(6.0 / float(fan_out + fan_in))
@@ -285,6 +285,13 @@ class EgoM2P(nn.Module):
     @torch.jit.ignore
     def no_weight_decay(self):
         return set()
+
+    def state_dict(self, *args, **kwargs):
+        """Reference key layout and shapes.  With a padded storage layout (the registered ego-L / ego-XL: Engine docstring) the
+        attention weights are exposed as per-head views as PARAMETERS; the state dict holds them in the reference's 2-D shape."""
+        if self.engine is not None and self.engine.padded and not args and not kwargs.get("prefix"):
+            return dict(self.engine.state_dict())
+        return super().state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         self.engine.load_state_dict(state_dict)              # skips (and returns) keys it has no storage for
@@ -382,8 +389,11 @@ def _swiglu_variant(dim, depth, heads):
     return fn
 
 
+# large / xlarge (egom2p_model.py:1080-1118: dim 1020 = 15 heads of 68, dim 2046 = 31 heads of 66) run on padded storage: rows of
+# 1024 / 2048, heads of 128, the ego_attn_*_hd kernels (engine.py) - parity configurations; the throughput ego-L is ego_L_1152
 for _n, _a in {"egom2p_tiny_6e_6d_swiglu_nobias": (384, 6, 6), "egom2p_small_8e_8d_swiglu_nobias": (512, 8, 8),
-               "egom2p_base_12e_12d_swiglu_nobias": (768, 12, 12)}.items():
+               "egom2p_base_12e_12d_swiglu_nobias": (768, 12, 12), "egom2p_large_24e_24d_swiglu_nobias": (1020, 24, 15),
+               "egom2p_xlarge_24e_24d_swiglu_nobias": (2046, 24, 31)}.items():
     _f = _swiglu_variant(*_a)
     _f.__name__ = _n
     register_model(_f)
@@ -399,8 +409,6 @@ def _unsupported(name, why):
 for _n in ("egom2p_tiny_6e_6d_gelu", "egom2p_small_8e_8d_gelu", "egom2p_base_12e_12d_gelu", "egom2p_large_24e_24d_gelu",
            "egom2p_xlarge_24e_24d_gelu"):
     register_model(_unsupported(_n, "GELU / biased variant"))
-for _n in ("egom2p_large_24e_24d_swiglu_nobias", "egom2p_xlarge_24e_24d_swiglu_nobias"):
-    register_model(_unsupported(_n, "dim 1020 / 2046 (head_dim 68 / 66) is not MFMA-tileable; use the aligned ego_L_1152 config"))
 for _n in ("egom2p_base_12e_12d_swiglu_nobias_causal", "egom2p_base_12e_12d_swiglu_qknorm_nobias",
            "egom2p_large_24e_24d_swiglu_qknorm_nobias", "egom2p_xlarge_24e_24d_swiglu_qknorm_nobias"):
     register_model(_unsupported(_n, "causal / qk-norm variant"))

@@ -198,6 +198,26 @@ def test_hipgraph_replay_is_bitwise_identical():
     assert torch.equal(a, b)
 
 
+def test_padded_geometry_inference_pass_equals_the_training_path():
+    """The registered ego-L geometry (dim 1020, 15 heads of 68: rows of 1024, heads of 128, ego_attn_*_hd kernels) on the
+    generation path: one `infer_logits` pass (rgb inputs -> gaze targets) gives the logits of the training-path forward of
+    the same clip - which tests/golden/L1020.npz pins to the reference - and replays bit for bit from a captured graph."""
+    cfg = MODEL_CFGS["ego_L_1020_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=256, n_dec=30)
+    eng.init_random(2)
+    budgets = {"tok_rgb": [(256, 0)], "tok_depth": [(0, 0)], "tok_cam": [(0, 0)], "tok_gaze": [(0, 30)]}
+    md = synth.make_clip_batch(cfg, 1, budgets, seed=12)
+    mdg = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in md.items()}
+    train = eng.forward_logits(mdg, dec_order=[m.name for m in cfg.mods])["tok_gaze"].float()
+    ids = mdg["tok_rgb"]["tensor"].reshape(1, -1)
+    pos = (~mdg["tok_gaze"]["target_mask"]).nonzero()[:, 1][None]              # ascending = the compaction's row order
+    assert pos.shape == (1, 30)
+    enc = {"tok_rgb": (ids, mdg["tok_rgb"]["input_mask"].reshape(1, -1))}
+    infer = eng.infer_logits(enc, 256, "tok_gaze", pos).float().clone()
+    assert torch.isfinite(infer).all() and rel_l2(infer.cpu().numpy(), train.cpu().numpy()) < 2e-3
+    assert torch.equal(eng.infer_logits_graphed(enc, 256, "tok_gaze", pos).float(), infer)
+
+
 @pytest.mark.parametrize("cfg_name,cond,target,n_target,steps", [
     ("ego_gen_384_2e_2d", "tok_rgb", "tok_depth", 5120, 3),          # eval_model_rgb2depth.py
     ("ego_b_2e_2d", "tok_rgb", "tok_gaze", 30, 5),                   # eval_model_rgb2gaze.py (sequence target, four modalities)

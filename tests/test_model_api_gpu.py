@@ -86,6 +86,58 @@ def test_gradients_visible_through_param_grad_and_no_sync_accumulates():
             assert rel_l2(got, g[key]) < 4e-2, (n, rel_l2(got, g[key]))
 
 
+def test_registered_ego_l_geometry_through_the_module_surface():
+    """dim 1020, 15 heads of 68 (egom2p_large_24e_24d_swiglu_nobias, egom2p_model.py:1080-1092; here at 2 + 2 layers, the
+    depth of tests/golden/L1020.npz): the module keeps the reference's key layout and state-dict shapes on the padded
+    storage, loss / clipped norm / AdamW step follow the reference's, and the storage pads stay exact zeros."""
+    assert {"egom2p_large_24e_24d_swiglu_nobias", "egom2p_xlarge_24e_24d_swiglu_nobias"} <= set(list_models())
+    g, meta = load_golden("L1020")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    mods = ["tok_rgb", "tok_depth", "tok_cam", "tok_gaze"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    model = EgoM2P(enc, dec, {m: MODALITY_INFO[m] for m in mods}, dim=1020, encoder_depth=2, decoder_depth=2, num_heads=15,
+                   mlp_ratio=4, qkv_bias=False, proj_bias=False, mlp_bias=False,
+                   norm_layer=partial(LayerNorm, eps=1e-6, bias=False), act_layer=nn.SiLU, gated_mlp=True)
+    eng = model.engine
+    assert eng.padded and (eng.D, eng.HDP) == (1024, 128)
+    assert sum(p.numel() for p in model.parameters()) == eng.num_params() == sum(v.numel() for k, v in sd.items()
+                                                                                 if not k.endswith("pos_emb") and not (k.endswith(".bias") and "norm" in k)
+                                                                                 and not (k.startswith("decoder_embeddings") and k.endswith(("mod_emb", "to_logits.weight"))))
+    # the constructor's init left the pads at zero and drew the reference's xavier bound for the (3 x [1020, 1020]) qkv
+    rest = eng.P.clone()
+    for n, (o, cnt, shape) in eng.offsets.items():
+        eng._logical(n, rest[o:o + cnt].view(shape)).zero_()
+    assert not bool(rest.any())
+    qkv = dict(model.named_parameters())["encoder.0.attn.qkv.weight"]
+    assert tuple(qkv.shape) == (3, 15, 68, 1020) and abs(float(qkv.detach().abs().max()) - (6.0 / 2040) ** 0.5) < 1e-3
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd)
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape) and torch.equal(v.float().cpu(), sd[k]), k
+    args = types.SimpleNamespace(opt="adamw", lr=meta["lr"], weight_decay=meta["wd"], opt_betas=(0.9, 0.95), opt_eps=1e-8)
+    opt = create_optimizer(args, model)
+    scaler = NativeScalerWithGradNormCount(enabled=False)
+    random.seed(meta["py_seed"])
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    loss, mod_loss = model(mdg, num_encoder_tokens=meta["n_enc"], num_decoder_tokens=meta["n_dec"], loss_type="mod")
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * float(g["loss"])
+    opt.zero_grad()
+    norm = scaler(loss, opt, clip_grad=1.0, parameters=model.parameters(), update_grad=True)
+    assert abs(norm.item() - float(g["clip_total_norm"])) < 2e-2 * float(g["clip_total_norm"])
+    new = model.state_dict()
+    for key in g.files:
+        if key.startswith("adamw."):
+            n = key.split(".", 1)[1]
+            assert np.abs(new[n].float().cpu().numpy().reshape(g[key].shape) - g[key]).max() <= 2.2 * meta["lr"], n
+    rest = eng.P.clone()
+    for n, (o, cnt, shape) in eng.offsets.items():
+        eng._logical(n, rest[o:o + cnt].view(shape)).zero_()
+    assert not bool(rest.any())
+
+
 def test_registry_and_scope_errors():
     assert "egom2p_base_12e_12d_swiglu_nobias" in list_models()
     mods = ["tok_rgb", "tok_depth", "tok_cam", "tok_gaze"]
