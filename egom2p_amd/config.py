@@ -95,6 +95,9 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     # the REGISTERED ego-L geometry (egom2p_model.py:1080-1092: dim 1020, 15 heads of 68, F = 2720) at parity-test depth;
     # stored in rows of 1024 with heads padded to 128 (engine.py) and run by the ego_attn_*_hd kernels
     "ego_L_1020_2e_2d": ModelCfg("ego_L_1020_2e_2d", 1020, 2, 2, 15),
+    # the registered ego-XL geometry (egom2p_model.py:1100-1118: dim 2046, 31 heads of 66, F = 5456) at parity-test depth:
+    # rows of 2048, heads of 128, F padded to 5504 (the fused SwiGLU backward needs F % 256: this shape takes the two-call form)
+    "ego_XL_2046_1e_1d": ModelCfg("ego_XL_2046_1e_1d", 2046, 1, 1, 31),
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),
     # config 4 (rgb -> depth generation) at ego-b width: D = 768, 12 heads of 64, F = 2048, at parity-test depth
     "ego_b_gen_2e_2d": ModelCfg("ego_b_gen_2e_2d", 768, 2, 2, 12, modalities=("tok_rgb", "tok_depth")),

@@ -14,7 +14,7 @@ constexpr int LN_MAXC_MAX = 8;   // float4 chunks per lane -> D <= 2048 (kernels
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward: y(bf16) = (x - mean) * rstd * w ; optional output row permutation
 // ---------------------------------------------------------------------------------------------
-template <int LN_MAXC>
+template <int LN_MAXC, bool TAIL>   // TAIL: D % 4 != 0 - the last chunk holds pad columns, masked element-wise
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      bf16_t* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, const int* __restrict__ out_row,
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= rows) return;
     // D = the normalised width, ld >= D = the row pitch of x and y (a model dimension stored padded: the columns [D, ld) of
     // x are zero and do not take part; those of y are written as zeros)
-    const int nc = D >> 2, ncl = ld >> 2;
+    const int nc = (D + 3) >> 2, ncl = ld >> 2;
     const float* xr = x + (long)row * ld;
     f32x4 v[LN_MAXC];
     float s = 0.f;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const int c = lane + 64 * i;
         if (c < nc) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += (!TAIL || c * 4 + e < D) ? d * d : 0.f; }
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (c < nc) {
             const f32x4 ww = *(const f32x4*)(w + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[i][e] = round_bf16((v[i][e] - mean) * rstd * ww[e]); amax = fmaxf(amax, fabsf(v[i][e])); }
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = (!TAIL || c * 4 + e < D) ? round_bf16((v[i][e] - mean) * rstd * ww[e]) : 0.f;
+                amax = fmaxf(amax, fabsf(v[i][e]));
+            }
             u32x2 o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3])};
             *(u32x2*)(yr + c * 4) = o;
         } else if (c < ncl) {
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wave)
 
-template <int LN_MAXC>
+template <int LN_MAXC, bool TAIL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const int* __restrict__ dy_row,
                                                      const float* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ w,
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dw_part, int rows, int D, int ld) {
     __shared__ float red[4][LN_MAXC * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nc = D >> 2, ncl = ld >> 2;      // D = normalised width, ld = row pitch (columns [D, ld): zero gradient)
+    const int nc = (D + 3) >> 2, ncl = ld >> 2;      // D = normalised width, ld = row pitch (columns [D, ld): zero gradient)
     f32x4 ww[LN_MAXC], dwa[LN_MAXC];
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (c < nc) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
+                for (int e = 0; e < 4; ++e) o[e] = (!TAIL || c * 4 + e < D) ? rstd * (g[i][e] - c1 - xh[i][e] * c2) : 0.f;
                 if (dx_in) o += *(const f32x4*)(dx_in + (long)row * ld + c * 4);
                 *(f32x4*)(dx_out + (long)row * ld + c * 4) = o;
                 if (dx_bf16) {
@@ -572,10 +575,12 @@ extern "C" int ego_layernorm_fwd(const float* x, const float* w, void* y, float*
                                  const int* out_row, int rows, int D, long ld, float eps, void* q8, long ldq, float* qscale,
                                  hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D <= 0 || D % 4 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || (q8 && (!qscale || ldq % 4 || ld != D))) return EGO_ERR_ARG;
-#define LN_FWD(C) EGO_LAUNCH(ln_fwd_kernel<C>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, (int)ld, eps, \
+    if (D <= 0 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || (q8 && (!qscale || ldq % 4 || ld != D))) return EGO_ERR_ARG;
+#define LN_FWD_(C, T) EGO_LAUNCH((ln_fwd_kernel<C, T>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, w, (bf16_t*)y, mean, rstd, out_row, rows, D, (int)ld, eps, \
                              (unsigned char*)q8, ldq, qscale)
+#define LN_FWD(C) do { if (D % 4) LN_FWD_(C, true); else LN_FWD_(C, false); } while (0)
     if (ld <= 768) LN_FWD(3); else if (ld <= 1024) LN_FWD(4); else if (ld <= 1536) LN_FWD(6); else LN_FWD(8);
+#undef LN_FWD_
 #undef LN_FWD
     LAUNCH_CHECK();
     return EGO_OK;
@@ -588,12 +593,14 @@ extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float*
                                  void* dx_bf16, float* dw, float* work, long work_floats, int rows, int D, long ld,
                                  hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (D <= 0 || D % 4 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || !work || work_floats < ego_layernorm_bwd_work_floats(rows, D))
+    if (D <= 0 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256 || !work || work_floats < ego_layernorm_bwd_work_floats(rows, D))
         return EGO_ERR_ARG;
     const int nwg = (rows + LNB_ROWS - 1) / LNB_ROWS;
-#define LN_BWD(C) EGO_LAUNCH(ln_bwd_kernel<C>, dim3(nwg), dim3(256), 0, stream, (const bf16_t*)dy, \
+#define LN_BWD_(C, T) EGO_LAUNCH((ln_bwd_kernel<C, T>), dim3(nwg), dim3(256), 0, stream, (const bf16_t*)dy, \
                        dy_row, x, mean, rstd, w, dx_in, dx_out, (bf16_t*)dx_bf16, work, rows, D, (int)ld)
+#define LN_BWD(C) do { if (D % 4) LN_BWD_(C, true); else LN_BWD_(C, false); } while (0)
     if (ld <= 768) LN_BWD(3); else if (ld <= 1024) LN_BWD(4); else if (ld <= 1536) LN_BWD(6); else LN_BWD(8);
+#undef LN_BWD_
 #undef LN_BWD
     LAUNCH_CHECK();
     ColsumDst dst{};

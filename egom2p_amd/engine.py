@@ -80,7 +80,7 @@ class Engine:
             self.HDP = 64
         else:
             fits = [h for h in (96, 128) if h >= self.HD and (self.H * h) % 128 == 0]
-            if cfg.dim % 4 or not fits:
+            if not fits:
                 raise L.EgoHipError(f"no storage layout for dim={cfg.dim}, heads={cfg.num_heads} x {self.HD}")
             self.HDP = fits[0]
         self.A = self.H * self.HDP

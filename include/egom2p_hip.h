@@ -118,7 +118,8 @@ int ego_loss_perm(const int* seg, const int* canon, const int* slot, const int* 
  * out_row may be NULL (identity); -1 drops the row. mean/rstd are saved for the backward.  q8 / qscale (optional): the
  * row also leaves as e4m3 bytes + scale, exactly what ego_quant_fp8_rows would make of y (operand of an fp8 GEMM; ld == D).
  * D = the normalised width, ld >= D = the row pitch of x and y in elements (ld > D: a model dimension stored padded - the
- * registered ego-L's 1020 in rows of 1024; the columns [D, ld) of x must be zero, those of y are written as zeros). */
+ * registered ego-L's 1020 in rows of 1024; the columns [D, ld) of x must be zero, those of y are written as zeros; ld % 4 == 0,
+ * any D <= ld; w / dw hold at least D rounded up to 4 floats). */
 int ego_layernorm_fwd(const float* x, const float* w, void* y_bf16, float* mean, float* rstd, const int* out_row,
                       int rows, int D, long ld, float eps, void* q8, long ldq, float* qscale, hipStream_t stream);
 /* dx_out = (dx_in ? dx_in : 0) + LN'(dy); dw += sum_rows dy * xhat.  dy_row: same map as out_row.  The weight gradient goes

@@ -6,7 +6,7 @@ four hot-path files are loaded by file path under empty namespace stubs, as SURV
 describes.  Nothing from the reference is copied: this script *calls* its code and stores
 input-independent data (outputs on generator-made weights and clips) as fixtures.
 
-    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b12|L24|L1020]
+    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b12|L24|L1020|XL2046]
 
 Weights/clips come from `egom2p_amd.synth` (counter-based generator) so the GPU box can
 regenerate them bit-identically; fixtures hold integer outputs in full and float outputs as
@@ -273,6 +273,10 @@ CASES = {
                 seed=5, full_float=False, py_seed=15),
     # the registered ego-L geometry (dim 1020, 15 heads of 68, F = 2720: egom2p_model.py:1080-1092), 2+2 layers, canonical split
     "L1020": dict(cfg_name="ego_L_1020_2e_2d", batch=1, n_enc=2048, n_dec=2048, budgets=None, seed=10, full_float=False, py_seed=20),
+    # the registered ego-XL geometry (dim 2046, 31 heads of 66, F = 5456: egom2p_model.py:1100-1118), 1+1 layers, N = M = 1024
+    "XL2046": dict(cfg_name="ego_XL_2046_1e_1d", batch=1, n_enc=1024, n_dec=1024,
+                   budgets={"tok_rgb": (497, 497), "tok_depth": (497, 497), "tok_cam": (15, 15), "tok_gaze": (15, 15)},
+                   seed=11, full_float=False, py_seed=21),
     # full-depth ego-L at the throughput shape (BASELINE config 5: D = 1152, 18 heads of 64, F = 3072, 24 + 24 layers,
     # 1.19 B parameters), canonical split, B=1
     # (N = M = 1024: the fp32 autograd graph of 48 layers at 2048 x 2048 scores does not fit this container's 64 GB)

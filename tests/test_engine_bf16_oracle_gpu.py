@@ -33,7 +33,7 @@ LOSS_TOL = 3e-4
 # b12 = the registered full-depth ego-b (12e / 12d, 400 M parameters), L2 = ego-L width (D = 1152): three oracle passes of
 # one clip each (about a minute on the box's 16 host cores) - the full-size cases sit behind the tight bars too; L24 = the
 # full-depth ego-L of BASELINE config 5 (24e / 24d, D = 1152, 1.19 B parameters) at N = M = 1024
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b12", "L2", "L24", "L1020"])
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b12", "L2", "L24", "L1020", "XL2046"])
 def test_engine_matches_bf16_mode_oracle(case):
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]

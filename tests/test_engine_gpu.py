@@ -46,7 +46,8 @@ def _tap(g, key, t):
 
 # L1020 = the REGISTERED ego-L geometry (dim 1020, 15 heads of 68, F = 2720: egom2p_model.py:1080-1092) at 2 + 2 layers: stored in rows
 # of 1024 with heads padded to 128 (engine.py) - the pad columns must stay exact zeros in activations and gradients
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020"])
+# XL2046 = the registered ego-XL geometry (dim 2046, 31 heads of 66, F = 5456) at 1 + 1 layers, same storage scheme
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020", "XL2046"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim

@@ -331,7 +331,7 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
     assert _rel(gv, v.grad) < 2e-2, ("dv", _rel(gv, v.grad))
 
 
-@pytest.mark.parametrize("hd,hdp", [(68, 96), (68, 128), (96, 96), (120, 128)])
+@pytest.mark.parametrize("hd,hdp", [(68, 96), (68, 128), (66, 128), (96, 96), (120, 128)])
 @pytest.mark.parametrize("B,H,Nq,Nk,kind", [(2, 3, 200, 333, "ragged"), (1, 5, 1100, 1100, "blocks"), (2, 2, 30, 30, "pad"),
                                              (1, 2, 256, 512, "full"), (3, 2, 100, 160, "sample")])
 def test_attention_other_head_dims(hd, hdp, B, H, Nq, Nk, kind):
@@ -498,10 +498,12 @@ def test_cross_entropy():
     assert torch.equal(logits[:40], keep[:40]) and torch.equal(logits[240:], keep[240:])
 
 
-def test_layernorm_on_padded_rows():
-    """LayerNorm over D = 1020 columns stored in rows of 1024 (the registered ego-L): statistics over the 1020, pad columns
-    of the output and of the input gradient written as zeros, weight gradient of the 1020 only."""
-    rows, D, ld = 777, 1020, 1024
+@pytest.mark.parametrize("D,ld", [(1020, 1024), (2046, 2048), (126, 128)])
+def test_layernorm_on_padded_rows(D, ld):
+    """LayerNorm over D columns stored in rows of ld (the registered ego-L: 1020 in 1024; ego-XL: 2046 in 2048, where the last
+    16-byte chunk is half pad): statistics over the D, pad columns of the output and of the input gradient written as zeros,
+    weight gradient of the D only."""
+    rows = 777
     x = torch.zeros(rows, ld, device=DEV); x[:, :D] = torch.randn(rows, D, device=DEV) * 2 + 0.3
     w = torch.zeros(ld, device=DEV); w[:D] = torch.rand(D, device=DEV) + 0.5
     y = torch.full((rows, ld), 9.0, device=DEV, dtype=torch.bfloat16)

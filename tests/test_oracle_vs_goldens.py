@@ -20,7 +20,7 @@ FP32_TOL = 2e-5
 
 CASES = ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "L1020"]
 if os.environ.get("EGOM2P_SLOW") == "1":
-    CASES += ["b12", "L2", "L24"]
+    CASES += ["b12", "L2", "L24", "XL2046"]
 
 
 def _setup(case):
