@@ -464,19 +464,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         char* ea = smem + (curA == 0 ? 2 : curA - 1) * RA_BYTES;
         char* ebb = smem + (3 + (curB ^ 1)) * RA_BYTES;
         if constexpr (FP8) {
-            // C = sa[m] * sb[n] * acc: this lane's 8 rows (i) and 4 x 4 columns (j) of the tile
+            // C = sa[m] * sb[n] * acc: this lane's 8 rows (i) and 4 x 4 columns (j) of the tile.  All 12 scale loads are
+            // issued together and waited for once (24 registers - the operand fragments are dead here): one global-memory
+            // round trip per tile instead of four serialised ones (each wait also drains the next tile's operand DMA)
+            float ra[8];
+            f32x4 cb[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra[i] = p.sa[moff + min(row0 + grp * 128 + i * 16 + (lane & 15), M - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int tc = wc * 64 + j * 16 + (lane >> 4) * 4;                         // first of 4 tile columns
                 const int bn = EK == 3 ? (tc < 128 ? col0 + tc : p.N + col0 + tc - 128) : min(col0 + tc, p.N - 4);
-                const f32x4 cb = *(const f32x4*)(p.sb + bn);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float ra = p.sa[moff + min(row0 + grp * 128 + i * 16 + (lane & 15), M - 1)];    // (L1-resident re-read)
-                    acc[i][j] = acc[i][j] * (cb * ra);
-                }
-                __builtin_amdgcn_sched_barrier(0);                                         // keep the live set at one column group
+                cb[j] = *(const f32x4*)(p.sb + bn);
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j] = acc[i][j] * (cb[j] * ra[i]);
         }
         if constexpr (EK == 0) {
 #pragma unroll
