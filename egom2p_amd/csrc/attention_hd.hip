@@ -6,8 +6,10 @@
 //
 // These are the PARITY kernels of a configuration nobody trains at scale (only the 400 M checkpoint is released): same
 // math and the same operand layouts as the d64 family - S^T = K Q'^T with the query on the lane, per-lane online softmax,
-// O^T = V^T P^T on key-permuted fragments - but tiles are staged through LDS with plain loads and __syncthreads (no LDS-DMA
-// ring, no lazy softmax reference), and every key / query tile is visited.  The throughput shapes (head dim 64) never come here.
+// O^T = V^T P^T on key-permuted fragments (transposed operands by ds_read_b64_tr_b16 on the row-major tile) - but tiles are
+// staged through LDS by plain loads (the next tile's rows are fetched into registers while the current one is computed;
+// no LDS-DMA ring, no lazy softmax reference), and every key / query tile is visited.  The throughput shapes (head dim 64)
+// never come here.
 #include "common.h"
 #include "egom2p_hip.h"
 
@@ -42,45 +44,47 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int x) {
     return r;
 }
 
-// LDS tiles of 32 rows (keys or queries):
-//   natural    [32][HDP] bf16, row pitch HDP * 2 + 16 bytes - a lane reads its row's 16-byte fragment per k-step
-//   transposed [HDP][32] bf16, row pitch 80 bytes           - a lane reads dims' two 8-byte key groups per 16-key step
+// LDS tile of 32 rows (keys or queries): [32][HDP] bf16, row pitch HDP * 2 + 16 bytes.  A lane reads its row's 16-byte
+// fragment per k-step (row-major operand) or, for the transposed operand, two 4-row x 16-column blocks through
+// ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of the block's 4 rows).
 template <int HDP> struct Tile {
-    static constexpr int NPITCH = HDP * 2 + 16, TPITCH = 80;
-    static constexpr int NBYTES = 32 * NPITCH, TBYTES = HDP * TPITCH;
+    static constexpr int NPITCH = HDP * 2 + 16;
+    static constexpr int NBYTES = 32 * NPITCH;
     static constexpr int CHUNKS = 32 * (HDP / 8);              // 16-byte chunks of a tile
+    static constexpr int PER = (CHUNKS + 255) / 256;           // chunks per thread
 };
+template <int HDP> struct Pre { u32x4 v[Tile<HDP>::PER]; };   // one tile's rows on their way from global memory to LDS
 
-// rows [row0, row0 + 32) of a [nrows, *] bf16 matrix (row stride rs elements) -> natural and / or transposed tile; rows
-// past nrows read as zeros
-template <int HDP, bool NAT, bool TRN>
-__device__ __forceinline__ void load_tile(const bf16_t* base, long rs, int row0, int nrows, char* nat, char* trn, int tid) {
+// rows [row0, row0 + 32) of a [nrows, *] bf16 matrix (row stride rs elements); rows past nrows read as zeros
+template <int HDP>
+__device__ __forceinline__ void fetch(Pre<HDP>& pre, const bf16_t* base, long rs, int row0, int nrows, int tid) {
     typedef Tile<HDP> T;
-    for (int c = tid; c < T::CHUNKS; c += 256) {
-        const int row = c / (HDP / 8), ch = c % (HDP / 8);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < nrows) v = *(const u32x4*)(base + (long)(row0 + row) * rs + ch * 8);
-        if (NAT) *(u32x4*)(nat + row * T::NPITCH + ch * 16) = v;
-        if (TRN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                *(bf16_t*)(trn + (ch * 8 + 2 * e) * T::TPITCH + row * 2) = (bf16_t)(v[e] & 0xffff);
-                *(bf16_t*)(trn + (ch * 8 + 2 * e + 1) * T::TPITCH + row * 2) = (bf16_t)(v[e] >> 16);
-            }
-        }
+    for (int i = 0; i < T::PER; ++i) {
+        const int c = tid + 256 * i, row = c / (HDP / 8), ch = c % (HDP / 8);
+        pre.v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (c < T::CHUNKS && row0 + row < nrows) pre.v[i] = *(const u32x4*)(base + (long)(row0 + row) * rs + ch * 8);
+    }
+}
+template <int HDP>
+__device__ __forceinline__ void stash(const Pre<HDP>& pre, char* nat, int tid) {
+    typedef Tile<HDP> T;
+#pragma unroll
+    for (int i = 0; i < T::PER; ++i) {
+        const int c = tid + 256 * i, row = c / (HDP / 8), ch = c % (HDP / 8);
+        if (c < T::CHUNKS) *(u32x4*)(nat + row * T::NPITCH + ch * 16) = pre.v[i];
     }
 }
 
-// A fragment of the transposed tile for output block db, 16-row step x: dims row 32 db + (lane & 31), rows
-// {16x + 4hh .. +3} and {16x + 8 + 4hh .. +3} - the row permutation pack8() gives the B operand
+// Fragment of the TRANSPOSED tile for output block db, 16-row step x: dims row 32 db + (lane & 31), tile rows
+// {16x + 4hh .. +3} and {16x + 8 + 4hh .. +3} - the row permutation pack8() gives the B operand.  Group g = lane >> 4 covers
+// dims 32 db + 16 (g & 1) .. +15 for half hh = g >> 1; lane 4q + p of a group supplies the address of tile row q, dims 4p .. 4p+3.
 template <int HDP>
-__device__ __forceinline__ bf16x8 trn_frag(const char* trn, int db, int x, int lane) {
+__device__ __forceinline__ bf16x8 trn_frag(const char* nat, int db, int x, int lane) {
     typedef Tile<HDP> T;
-    const int hh = lane >> 5;
-    const char* p = trn + (32 * db + (lane & 31)) * T::TPITCH + (16 * x + 4 * hh) * 2;
-    const u32x2 lo = *(const u32x2*)p, hi = *(const u32x2*)(p + 16);
-    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8, v);
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+    const char* a0 = nat + (16 * x + 4 * (g >> 1) + q) * T::NPITCH + (32 * db + 16 * (g & 1) + 4 * pp) * 2;
+    return join8(lds_read_tr16(a0), lds_read_tr16(a0 + 8 * T::NPITCH));
 }
 template <int HDP>
 __device__ __forceinline__ bf16x8 nat_frag(const char* nat, int s, int lane) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
     typedef Tile<HDP> T;
     constexpr int KS = HDP / 16, DB = HDP / 32;
     __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Vt[T::TBYTES];
+    __shared__ __attribute__((aligned(16))) char Vn[T::NBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.Nq + 127) >> 7;
     const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -146,23 +150,35 @@ __global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
         for (int i = 0; i < 16; ++i) ot[db][i] = 0.f;
     float m = NEG_BIG, l = 0.f;
     const int nkt = (p.Nk + 31) >> 5;
+    Pre<HDP> pk, pv;
+    fetch<HDP>(pk, Kb, p.k_rs, 0, p.Nk, tid);
+    fetch<HDP>(pv, Vb, p.v_rs, 0, p.Nk, tid);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        load_tile<HDP, true, false>(Kb, p.k_rs, kt * 32, p.Nk, Kn, nullptr, tid);
-        load_tile<HDP, false, true>(Vb, p.v_rs, kt * 32, p.Nk, nullptr, Vt, tid);
-        __syncthreads();
+        lds_barrier();                                              // the previous tile's readers are done
+        stash<HDP>(pk, Kn, tid);
+        stash<HDP>(pv, Vn, tid);
+        if (kt + 1 < nkt) {                                         // the next tile flies while this one is computed
+            fetch<HDP>(pk, Kb, p.k_rs, (kt + 1) * 32, p.Nk, tid);   // (lds_barrier orders LDS only: __syncthreads would wait
+            fetch<HDP>(pv, Vb, p.v_rs, (kt + 1) * 32, p.Nk, tid);   //  for these loads)
+        }
+        lds_barrier();
         f32x16 st;
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
         float mx = NEG_BIG;
+        if (__all(kt * 32 >= ks && kt * 32 + 32 <= ke)) {           // the whole tile lies inside every row's interval
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kidx = kt * 32 + acc_row(r, hh);
-            const float v = (kidx >= ks && kidx < ke) ? st[r] : NEG_BIG;
-            st[r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kidx = kt * 32 + acc_row(r, hh);
+                const float v = (kidx >= ks && kidx < ke) ? st[r] : NEG_BIG;
+                st[r] = v;
+                mx = fmaxf(mx, v);
+            }
         }
         mx = xhalf_max(mx);
         const float mnew = fmaxf(m, mx);
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
         for (int x = 0; x < 2; ++x) {
             const bf16x8 pf = pack8(st, x);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Vt, db, x, lane), pf, ot[db], 0, 0, 0);
+            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Vn, db, x, lane), pf, ot[db], 0, 0, 0);
         }
     }
     const float lt = xhalf_sum(l);
@@ -229,7 +245,6 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
     constexpr int KS = HDP / 16, DB = HDP / 32;
     __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
     __shared__ __attribute__((aligned(16))) char Vn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Kt[T::TBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.Nq + 127) >> 7;
     const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -261,11 +276,18 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqt[db][i] = 0.f;
     const int nkt = (p.Nk + 31) >> 5;
+    Pre<HDP> pk, pv;
+    fetch<HDP>(pk, Kb, p.k_rs, 0, p.Nk, tid);
+    fetch<HDP>(pv, Vb, p.v_rs, 0, p.Nk, tid);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        load_tile<HDP, true, true>(Kb, p.k_rs, kt * 32, p.Nk, Kn, Kt, tid);
-        load_tile<HDP, true, false>(Vb, p.v_rs, kt * 32, p.Nk, Vn, nullptr, tid);
-        __syncthreads();
+        lds_barrier();
+        stash<HDP>(pk, Kn, tid);
+        stash<HDP>(pv, Vn, tid);
+        if (kt + 1 < nkt) {
+            fetch<HDP>(pk, Kb, p.k_rs, (kt + 1) * 32, p.Nk, tid);
+            fetch<HDP>(pv, Vb, p.v_rs, (kt + 1) * 32, p.Nk, tid);
+        }
+        lds_barrier();
         f32x16 st, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
@@ -274,17 +296,22 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Vn, s, lane), gf[s], dp, 0, 0, 0);
         }
+        if (__all(kt * 32 >= ks && kt * 32 + 32 <= ke)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kidx = kt * 32 + acc_row(r, hh);
-            const float pe = (kidx >= ks && kidx < ke) ? __builtin_amdgcn_exp2f(st[r] - lse2) : 0.f;
-            st[r] = pe * (dp[r] - delta);
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] - lse2) * (dp[r] - delta);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kidx = kt * 32 + acc_row(r, hh);
+                const float pe = (kidx >= ks && kidx < ke) ? __builtin_amdgcn_exp2f(st[r] - lse2) : 0.f;
+                st[r] = pe * (dp[r] - delta);
+            }
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const bf16x8 df = pack8(st, x);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Kt, db, x, lane), df, dqt[db], 0, 0, 0);
+            for (int db = 0; db < DB; ++db) dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Kn, db, x, lane), df, dqt[db], 0, 0, 0);
         }
     }
     if (q0 + ql < p.Nq)
@@ -300,10 +327,8 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
     constexpr int KS = HDP / 16, DB = HDP / 32;
     __shared__ __attribute__((aligned(16))) char Qn[T::NBYTES];
     __shared__ __attribute__((aligned(16))) char Gn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Qt[T::TBYTES];
-    __shared__ __attribute__((aligned(16))) char Gt[T::TBYTES];
-    __shared__ float a_lse[32], a_delta[32];
-    __shared__ int a_ks[32], a_ke[32];
+    __shared__ __attribute__((aligned(16))) float a_lse[32], a_delta[32];
+    __shared__ __attribute__((aligned(16))) int a_ks[32], a_ke[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.Nk + 127) >> 7;
     const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -332,21 +357,31 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkt[db][i] = 0.f; dvt[db][i] = 0.f; }
     const int nqt = (p.Nq + 31) >> 5;
-    for (int qt = 0; qt < nqt; ++qt) {
-        __syncthreads();
-        load_tile<HDP, true, true>(Qb, p.q_rs, qt * 32, p.Nq, Qn, Qt, tid);
-        load_tile<HDP, true, true>(Gb, p.do_rs, qt * 32, p.Nq, Gn, Gt, tid);
+    // the next query tile on its way: rows of Q and dO, and (threads 0-31) the tile's row constants
+    Pre<HDP> pq, pg;
+    float n_lse = 0.f, n_delta = 0.f;
+    int n_ks = 0, n_ke = 0;
+    auto fetch_tile = [&](int qt) {
+        fetch<HDP>(pq, Qb, p.q_rs, qt * 32, p.Nq, tid);
+        fetch<HDP>(pg, Gb, p.do_rs, qt * 32, p.Nq, tid);
         if (tid < 32) {
             const int q = qt * 32 + tid;
-            const bool in = q < p.Nq;
             const int qc = min(q, p.Nq - 1);
-            a_lse[tid] = p.LSE[lb + qc];
-            a_delta[tid] = p.DELTA[lb + qc];
-            int rks = p.ks[b * p.r_bs + qc * p.r_rs], rke = min(p.ke[b * p.r_bs + qc * p.r_rs], p.Nk);
-            if (!in) { rks = 0x7fffffff; rke = -1; }                    // a row past Nq sees no key (and is not "flat")
-            a_ks[tid] = rks; a_ke[tid] = rke;
+            n_lse = p.LSE[lb + qc];
+            n_delta = p.DELTA[lb + qc];
+            n_ks = p.ks[b * p.r_bs + qc * p.r_rs];
+            n_ke = min(p.ke[b * p.r_bs + qc * p.r_rs], p.Nk);
+            if (q >= p.Nq) { n_ks = 0x7fffffff; n_ke = -1; }             // a row past Nq sees no key (and is not "flat")
         }
-        __syncthreads();
+    };
+    fetch_tile(0);
+    for (int qt = 0; qt < nqt; ++qt) {
+        lds_barrier();
+        stash<HDP>(pq, Qn, tid);
+        stash<HDP>(pg, Gn, tid);
+        if (tid < 32) { a_lse[tid] = n_lse; a_delta[tid] = n_delta; a_ks[tid] = n_ks; a_ke[tid] = n_ke; }
+        if (qt + 1 < nqt) fetch_tile(qt + 1);
+        lds_barrier();
         f32x16 st, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
@@ -355,25 +390,48 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
             st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Qn, s, lane), kf[s], st, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Gn, s, lane), vf[s], dp, 0, 0, 0);
         }
+        // row constants of this lane's 16 query rows: acc_row(4g + e, hh) = 8g + 4hh + e, four consecutive rows per g
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const int kw0 = tile * 128 + wave * 32;
+        bool full;
+        {   // every row of the tile sees all 32 keys of this wave (no empty interval, no row past Nq, no key past Nk)?
+            const int rks = a_ks[kl], rke = a_ke[kl];
+            full = __all(rke > rks && rks <= kw0 && rke >= kw0 + 32) && kw0 + 32 <= p.Nk;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = acc_row(r, hh);
-            int rks = a_ks[q], rke = a_ke[q];
-            const bool past = rke < 0;
-            const bool flat = !past && rke <= rks;                      // empty interval: p = 1 / Nk, dS = 0
-            if (flat) { rks = 0; rke = p.Nk; }
-            const bool ok = !past && kidx >= rks && kidx < rke && kidx < p.Nk;
-            const float pe = ok ? __builtin_amdgcn_exp2f((flat ? 0.f : st[r]) - a_lse[q]) : 0.f;
-            st[r] = pe;
-            dp[r] = flat ? 0.f : pe * (dp[r] - a_delta[q]);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 L = *(const f32x4*)&a_lse[8 * g + 4 * hh], Dl = *(const f32x4*)&a_delta[8 * g + 4 * hh];
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pe = __builtin_amdgcn_exp2f(st[r] - L[e]);
+                    st[r] = pe;
+                    dp[r] = pe * (dp[r] - Dl[e]);
+                }
+            } else {
+                const i32x4 KS4 = *(const i32x4*)&a_ks[8 * g + 4 * hh], KE4 = *(const i32x4*)&a_ke[8 * g + 4 * hh];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    int rks = KS4[e], rke = KE4[e];
+                    const bool past = rke < 0;
+                    const bool flat = !past && rke <= rks;                  // empty interval: p = 1 / Nk, dS = 0
+                    if (flat) { rks = 0; rke = p.Nk; }
+                    const bool ok = !past && kidx >= rks && kidx < rke && kidx < p.Nk;
+                    const float pe = ok ? __builtin_amdgcn_exp2f((flat ? 0.f : st[r]) - L[e]) : 0.f;
+                    st[r] = pe;
+                    dp[r] = flat ? 0.f : pe * (dp[r] - Dl[e]);
+                }
+            }
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const bf16x8 pf = pack8(st, x), df = pack8(dp, x);
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Gt, db, x, lane), pf, dvt[db], 0, 0, 0);
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Qt, db, x, lane), df, dkt[db], 0, 0, 0);
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Gn, db, x, lane), pf, dvt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Qn, db, x, lane), df, dkt[db], 0, 0, 0);
             }
         }
     }
