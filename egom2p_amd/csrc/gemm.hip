@@ -259,6 +259,9 @@ __device__ __forceinline__ void bar_pinned() {
 // drain under the next tile.  Operands arrive by buffer loads (LDS-DMA): lane offsets are loop-invariant, tile and K
 // position are the scalar offset, rows past M / N read as zeros.  K >= 128.
 // cache policy of the operand DMAs (aux of buffer_load ... lds: 0 default, 2 = nt: streamed, evict-first in L2)
+#ifndef NT256_STRIPS
+#define NT256_STRIPS 1      // column-strip tile walk for wide outputs (0: row-major everywhere, the round-2 walk)
+#endif
 #ifndef NT256_A_AUX
 #define NT256_A_AUX 0
 #endif
@@ -281,7 +284,8 @@ __device__ __forceinline__ i32x8 cat_frag(bf16x8 lo, bf16x8 hi) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int EK, bool FP8 = false>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward, 3 fused SwiGLU forward (separate register allocations)
+// STRIPS: the column-strip tile walk of very wide outputs (its own instantiation: the narrow shapes keep the row-major code as is)
+template <int EK, bool FP8 = false, bool STRIPS = false>   // epilogue class: 0 bf16, 1 fp32 family, 2 fused SwiGLU backward, 3 fused SwiGLU forward (separate register allocations)
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     constexpr int ESZ = FP8 ? 1 : 2;                           // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,9 +323,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         b_off0 = (unsigned)((EK == 3 && r >= 128 ? p.N - 128 + r : r) * (int)p.ldb * ESZ + c);
     }
     const unsigned a_step = (unsigned)(8 * (int)p.lda * ESZ), b_step = (unsigned)(8 * (int)p.ldb * ESZ);
+    // Tile walk.  xcd_remap gives every XCD a contiguous run of tile indices t, and the 32 workgroups of an XCD work on 32
+    // consecutive t at a time.  Outputs of up to 31 column tiles: t runs row-major over the whole width - the 32 tiles are a
+    // few A row panels times all column tiles.  The 64,000-token logits (250 column tiles): row-major puts all 32 on ONE A
+    // panel with 32 different B panels (33 operand panels per 32 tiles, and the 98 MB table re-read for each of the 252 row
+    // panels: 24.7 GB per launch); there t walks down column STRIPS of about 8 tiles - 32 tiles = 4 A panels x 8 B panels,
+    // the strip's B panels stay the same from one round to the next, and what is re-read per strip is the 99 MB of A
+    // (Infinity-Cache resident).  Measured (tools/gemm_ab.py): logits 1005 -> 1102 TF/s; at 16 column tiles (fc1||fc3) strips
+    // are 2.5 % SLOWER (A, 201 MB, is then streamed from HBM once per strip), hence the threshold.
+    const int rows_t = (M + 255) / 256;
+    const int nstrips = STRIPS ? (tiles_n + 7) / 8 : 1;
+    const int w0 = tiles_n / nstrips, wide = tiles_n % nstrips;   // the first `wide` strips are w0 + 1 tiles wide
+    const int big = wide * (w0 + 1) * rows_t;
     auto tile_origin = [&](int id, int& row0, int& col0) {
         const int t = xcd_remap(id, ntiles);
-        row0 = (t / tiles_n) * 256; col0 = (t % tiles_n) * tile_w;
+        int tr, tc;
+        if constexpr (STRIPS) {
+            int rem, w, c0;
+            if (t < big) { const int per = (w0 + 1) * rows_t, sidx = t / per; rem = t - sidx * per; w = w0 + 1; c0 = sidx * (w0 + 1); }
+            else { const int per = w0 * rows_t, u = t - big, sidx = u / per; rem = u - sidx * per; w = w0; c0 = wide * (w0 + 1) + sidx * w0; }
+            tr = rem / w; tc = c0 + rem % w;
+        } else {
+            tr = t / tiles_n; tc = t % tiles_n;
+        }
+        row0 = tr * 256; col0 = tc * tile_w;
     };
     // fetch cursors: the K-tile of the stream that the next A / B DMA brings in (scalar state)
     int idA = blockIdx.x, ktA = 0, rA, cA_unused, slotA = 0; bool moreA = true;
@@ -1102,6 +1127,7 @@ void ensure_attrs() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
@@ -1146,7 +1172,9 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     const bool legal256 = N % 128 == 0 && K >= 2 * BK && 256L * lda * 2 < 0x7ff00000L && (long)N * ldb * 2 < 0xfff00000L;
     const bool big = legal256 && (g_nt256 == 2 || (g_nt256 == 1 && (tiles256 >= 640 || (K >= 2048 && tiles256 >= 160))));
     if (big) {
-        if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+        if (epi == EGO_EPI_BF16 && NT256_STRIPS && (N + 255) / 256 >= 32) {              // the 64,000-token logits: column-strip walk
+            EGO_LAUNCH((gemm_nt256_kernel<0, false, true>), dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
+        } else if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
         else { EGO_LAUNCH(gemm_nt256_kernel<1>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
         LAUNCH_CHECK();
         return EGO_OK;
