@@ -128,17 +128,35 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int x) {
 // accumulator row index (0..31) of register r for lane half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// store a transposed 64(d) x 32(rows on lanes) accumulator pair as bf16 rows [row][64 d]
+#ifndef ATT_WIDE_STORE
+#define ATT_WIDE_STORE 1
+#endif
+// Two 8-dim groups (g0, g1) of a row, 4 dims each held by the lane and 4 by its partner lane ^ 32 (same row, other half):
+// one v_permlane32_swap per dword leaves the lower-half lane with all 8 dims of g0 and the upper-half lane with all 8 of
+// g1 - one 16-byte store per lane instead of two 8-byte ones (the store tail is issue-bound: half the instructions).
+__device__ __forceinline__ void store_pair16(bf16_t* row, int g0, u32x2 a, u32x2 b, int hh) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+    *(u32x4*)(row + 8 * (g0 + hh)) = v;
+}
+
+// store a transposed 64(d) x 32(rows on lanes) accumulator pair as bf16 rows [row][64 d] (rows 16-byte aligned)
 __device__ __forceinline__ void store_rows_bf16(bf16_t* dst, const f32x16 (&t)[2], float mul, int hh) {
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db) {
+        u32x2 o[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = db * 32 + 8 * g + 4 * hh;
-            u32x2 o = {pack_bf16x2(t[db][4 * g] * mul, t[db][4 * g + 1] * mul),
-                       pack_bf16x2(t[db][4 * g + 2] * mul, t[db][4 * g + 3] * mul)};
-            *(u32x2*)(dst + d0) = o;
-        }
+        for (int g = 0; g < 4; ++g)
+            o[g] = u32x2{pack_bf16x2(t[db][4 * g] * mul, t[db][4 * g + 1] * mul), pack_bf16x2(t[db][4 * g + 2] * mul, t[db][4 * g + 3] * mul)};
+#if ATT_WIDE_STORE
+        store_pair16(dst + db * 32, 0, o[0], o[1], hh);
+        store_pair16(dst + db * 32, 2, o[2], o[3], hh);
+#else
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(u32x2*)(dst + db * 32 + 8 * g + 4 * hh) = o[g];
+#endif
+    }
 }
 
 // K / V (or Q / dO) tiles go straight from global memory into LDS (LDS-DMA, no VGPR staging): wave instruction i of
@@ -171,18 +189,27 @@ __device__ __forceinline__ void dma_tile64(__amdgpu_buffer_rsrc_t rsrc, long rs,
 // the same rows as two bf16 numbers per element: hi = bf16(x), lo = bf16(x - hi) (x to ~16 significant bits)
 __device__ __forceinline__ void store_rows_bf16_hilo(bf16_t* hi, bf16_t* lo, const f32x16 (&t)[2], float mul, int hh) {
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db) {
+        u32x2 o[4], q[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int d0 = db * 32 + 8 * g + 4 * hh;
             float x[4], r[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { x[e] = t[db][4 * g + e] * mul; r[e] = x[e] - round_bf16(x[e]); }
-            u32x2 o = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
-            u32x2 q = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
-            *(u32x2*)(hi + d0) = o;
-            *(u32x2*)(lo + d0) = q;
+            o[g] = u32x2{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+            q[g] = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
         }
+#if ATT_WIDE_STORE
+        store_pair16(hi + db * 32, 0, o[0], o[1], hh); store_pair16(hi + db * 32, 2, o[2], o[3], hh);
+        store_pair16(lo + db * 32, 0, q[0], q[1], hh); store_pair16(lo + db * 32, 2, q[2], q[3], hh);
+#else
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(u32x2*)(hi + db * 32 + 8 * g + 4 * hh) = o[g];
+            *(u32x2*)(lo + db * 32 + 8 * g + 4 * hh) = q[g];
+        }
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -888,7 +915,7 @@ extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a) || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
+    if (!check(a) || o_rs % 8 || o_bs % 8 || (((uintptr_t)O) & 15) || (((uintptr_t)O_lo) & 15)) return EGO_ERR_ARG;    // 16-byte output rows
     EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
@@ -911,7 +938,8 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 || o_rs % 4 || o_bs % 4) return EGO_ERR_ARG;
+    if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 || o_rs % 4 || o_bs % 4 ||
+        ((((uintptr_t)dQ) | ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;                              // 16-byte gradient rows
     if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
 #ifndef ATT_ONLY
 #define ATT_ONLY 0                      // timing builds: 1 = dQ kernel only, 2 = dK / dV kernel only

@@ -161,7 +161,8 @@ int ego_gemm_nt_swiglu_fwd_fp8(const void* X8, long ldx, const float* sx, const 
 int ego_gemm_tn_plan(int Ni, int Nj, int M, long ldp, long ldq, long slab_elems, int ranged);
 
 /* Fused attention, head_dim 64 (Attention / CrossAttention, egom2p_utils.py:185-205, 222-244).
- * Element (b, row, head h, d) of X at X + b * x_bs + row * x_rs + h * 64 + d.  ks/ke: allowed key
+ * Element (b, row, head h, d) of X at X + b * x_bs + row * x_rs + h * 64 + d; every tensor 16-byte aligned with batch and
+ * row strides that are multiples of 8 elements (16-byte row fragments in and out), else EGO_ERR_ARG.  ks/ke: allowed key
  * interval of query row (b, q) at [b * r_bs + q * r_rs] (r_rs = 0: one interval per sample).
  * LSE: fp32 [B, H, Nq], MINUS the log2-domain log-sum-exp of the scaled scores (an opaque hand-over from the forward to
  * the backward, which uses it - and DELTA, MINUS rowsum(dO o O), written by the backward's first kernel - as the initial
