@@ -28,6 +28,8 @@ BF16_STORE = 2.5e-3     # a tap the engine keeps in bf16 carries one more roundi
 GRAD_TOL = 1e-2
 SENS_FACTOR = 2.5       # a gradient may differ from the bf16 oracle by 2.5 x the tensor's own bf16 sensitivity (see below)
 LOSS_TOL = 3e-4
+LOGIT_TOL = 7.5e-3      # logits = bf16(dec_out_bf16 @ W_bf16): the dec_out bar (5e-3 + 2.5e-3), the output rounding adds in quadrature
+LOGIT_ROWS = 64
 
 
 # b12 = the registered full-depth ego-b (12e / 12d, 400 M parameters), L2 = ego-L width (D = 1152): three oracle passes of
@@ -46,6 +48,15 @@ def test_engine_matches_bf16_mode_oracle(case):
     eng.load_state_dict(sd)
     mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
     loss, mod_loss = eng.forward(mdg, dec_order=order)
+    # training-path logits (north_star's "outputs"): full rows of the first LOGIT_ROWS rows of every modality, taken before
+    # the backward turns the buffer into d logits.  Row r of modality c (in (clip, decoder position) order, the order of the
+    # reference's y[decoder_mod_mask == id], egom2p_model.py:633) sits where the final LayerNorm wrote it: perm[flat index].
+    got_logits = {}
+    dmm = eng.cd["mod_mask"][:B].view(-1).long()
+    for c, m in enumerate(cfg.mods):
+        sel = (dmm == m.id).nonzero()[:, 0][:LOGIT_ROWS]
+        if sel.numel():
+            got_logits[m.name] = eng.logits[m.vocab_size][eng.perm[:B * M].long()[sel]].float().cpu()
     eng.zero_grad()
     eng.backward(1.0)
     torch.cuda.synchronize()
@@ -92,6 +103,13 @@ def test_engine_matches_bf16_mode_oracle(case):
     perm = eng.perm[:RM].view(B, M).cpu()[dkeep].long()
     errs["dec_out"] = (rel_l2(eng.yn[perm.cuda()][:, :D].float().cpu().numpy(), taps["dec_out"].detach()[dkeep].numpy()),
                        ACT_TOL + BF16_STORE)                       # stored in bf16
+    for m in cfg.mods:
+        ref_lg = taps[f"logits.{m.name}"].detach().float()
+        assert (m.name in got_logits) == (ref_lg.shape[0] > 0), m.name
+        if m.name in got_logits:
+            g_lg = got_logits[m.name]
+            assert g_lg.shape[0] == min(LOGIT_ROWS, ref_lg.shape[0])
+            errs[f"logits.{m.name}"] = (rel_l2(g_lg.numpy(), ref_lg[:g_lg.shape[0]].numpy()), LOGIT_TOL)
     print(case, {k: f"{v[0]:.2e}" for k, v in errs.items()})
     for k, (e, tol) in errs.items():
         assert e < tol, (case, k, e, tol)

@@ -143,9 +143,16 @@ def test_roar_cfg_generation_matches_reference(fixture):
         # u + 2 (c - u) up to 2.5 ulps of the largest logits - so a differing token must sit within 3 bf16 ulps of the largest
         # mixed logit (ulp(x) = 2^(floor(log2 x) - 7); peaked heads have logits in the thousands: ulp 8 - 16), or within 0.35
         # for the small flat-head logits.  Measured: exactly 20.0 = 2.5 ulps of 8 at |logit| 1136 on the full-depth fixture.
-        top = float(mixed.abs().max())
-        gap_bar = max(0.35, 3.0 * 2.0 ** (np.floor(np.log2(max(top, 1e-30))) - 7))
-        assert gap.max().item() <= gap_bar, (step, gap.max().item(), gap_bar, top)
+        # The bar is per ROW: 3 ulps of THAT row's largest |mixed logit|, not of the global maximum; the rows
+        # that exceed the round-2 bar 0.35 * max(1, 0.02 * row top) are counted and printed for the record.
+        row_top = mixed.abs().max(-1).values.clamp_min(1e-30)
+        row_bar = torch.clamp(3.0 * torch.exp2(torch.floor(torch.log2(row_top)) - 7), min=0.35)
+        old_bar = 0.35 * torch.clamp(0.02 * row_top, min=1.0)
+        over_old = int((gap[:, 0] > old_bar).sum())
+        if over_old:
+            print(fixture, "step", step, "rows over the round-2 gap bar:", over_old, "of", gap.shape[0], "max gap", gap.max().item())
+        worst = int((gap[:, 0] - row_bar).argmax())
+        assert bool((gap[:, 0] <= row_bar).all()), (step, gap[worst, 0].item(), row_bar[worst].item(), row_top[worst].item())
     # random-init weights give nearly flat logits: bf16 noise flips near-ties there (the gap bound above is the real bar);
     # with the peaked head the sampled tokens themselves agree
     print(fixture, "sampled-token agreement", round(agree_total / n_total, 4))
