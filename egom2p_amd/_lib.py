@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOM2P_HIP_LIB", os.path.join(_HERE, "libegom2p_hip.so"))   # override: kernel experiments
 MAX_MODS = 8
 
-ABI_VERSION = 4          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
+ABI_VERSION = 5          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
 EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -23,7 +23,7 @@ class CompactDesc(C.Structure):
         ("mask", vp * MAX_MODS), ("ids", vp * MAX_MODS), ("dam", vp * MAX_MODS),
         ("n_pos", i32 * MAX_MODS), ("mod_id", i32 * MAX_MODS),
         ("ids_keep", vp), ("pad", vp), ("mod_mask", vp), ("slot", vp), ("local", vp), ("tok", vp),
-        ("ks", vp), ("ke", vp), ("n_valid", vp), ("seg", vp), ("err", vp),
+        ("ks", vp), ("ke", vp), ("n_valid", vp), ("seg", vp), ("err", vp), ("seg_bad", vp),
     ]
 
 
@@ -57,6 +57,7 @@ class EmbedBwdDesc(C.Structure):
 _SIGS = {
     "ego_abi_version": [],
     "ego_gemm_kernel_mode": [i32, i32],
+    "ego_gemm_small_tiles": [i32],
     "ego_compact": [C.POINTER(CompactDesc), i32, vp],
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
     "ego_embed_bwd_work_floats": [i64, i32, i32],
@@ -78,6 +79,10 @@ _SIGS = {
                          i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
                          vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
+    "ego_attn_fwd_d64_seg": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64, vp, i32, vp,
+                             i32, i32, i32, i32, f32, vp],
+    "ego_attn_bwd_d64_seg": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
+                             vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, i32, vp, i32, i32, i32, i32, f32, vp],
     "ego_attn_fwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64,
                         i32, i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
@@ -89,9 +94,10 @@ _SIGS = {
     "ego_gemm_nt_swiglu_bwd": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp],
     "ego_gemm_nt_swiglu_fwd": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "ego_ce_fwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp],
-    "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp],
-    "ego_ce_fwd_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp, i32, vp],
-    "ego_loss_finalize": [vp, vp, i32, vp, vp, vp],
+    "ego_ce_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, i32, vp, vp],
+    "ego_ce_fwd_bwd": [vp, i64, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp],
+    "ego_loss_weights": [vp, C.POINTER(i32), i32, i32, vp, vp, vp],
+    "ego_loss_finalize": [vp, vp, i32, vp, vp, vp, vp, vp],
     "ego_cast_weight": [vp, i32, i32, i64, vp, i64, vp, i64, i32, vp],
     "ego_cast_f32_bf16": [vp, vp, i64, vp],
     "ego_bias_grad_work_floats": [i64, i32],
@@ -139,6 +145,8 @@ def load():
         # reads no environment; this is the same call tests make through ops.gemm_kernel_mode)
         if "EGO_GEMM_NT256" in os.environ or "EGO_GEMM_TN256" in os.environ:
             lib.ego_gemm_kernel_mode(int(os.environ.get("EGO_GEMM_NT256", "1")), int(os.environ.get("EGO_GEMM_TN256", "1")))
+        if "EGO_GEMM_SMALL_TILES" in os.environ:
+            lib.ego_gemm_small_tiles(int(os.environ["EGO_GEMM_SMALL_TILES"]))
         _lib = lib
     return _lib
 

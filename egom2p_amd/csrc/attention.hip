@@ -35,6 +35,10 @@ struct AttnArgs {
     float* LSE;                 // [B,H,Nq] MINUS the log2-domain log-sum-exp of the scaled scores (the backward's accumulator init)
     const int* ks; const int* ke;  // interval of query row (b,q) at [b*r_bs + q*r_rs]
     long r_bs, r_rs;
+    // row groups (self-attention under a block-diagonal mask; optional): seg[b][g] = (first row, row count) of group g of
+    // sample b, groups ascending and disjoint; every row of a group attends exactly the group's own row range.  Rows behind
+    // the last group (and all rows of a sample with seg_bad[b] != 0) take the per-row intervals ks / ke.
+    const int* seg; const int* seg_bad; int n_seg;
     int B, H, Nq, Nk;
     float scale;
     // backward only
@@ -65,6 +69,33 @@ __device__ __forceinline__ void pair_tile(int id, int pairs, int tiles, bool wal
         pair = id % pairs;
         tile = id / pairs;
     }
+}
+
+// Row-group launches: tile index t of sample b -> the group it belongs to.  Groups are cut into 128-row tiles of their own
+// (a tile never straddles two groups, so all its rows share one interval: the uniform fast path of the kernels); what is left
+// of the tile index space covers the rows behind the last group ("tail": per-row intervals), tile by tile.  Returns false when
+// the tile index is beyond the sample's tiles.  g0 / g1 = row range of the group (or of the tail), t = tile inside it.
+struct GroupTile { int g0, g1, t; bool uniform; int tail0; };
+__device__ __forceinline__ bool group_tile(const AttnArgs& p, int b, int tile, int n_rows, GroupTile& g) {
+    int tail0 = 0;
+    bool found = false;
+    g.uniform = false;
+    if (!(p.seg_bad && p.seg_bad[b])) {
+        for (int i = 0; i < p.n_seg; ++i) {
+            const int s0 = p.seg[((long)b * p.n_seg + i) * 2], c = p.seg[((long)b * p.n_seg + i) * 2 + 1];
+            const int nt = (c + 127) >> 7;
+            if (!found) {
+                if (tile < nt) { found = true; g.g0 = s0; g.g1 = s0 + c; g.t = tile; g.uniform = true; }
+                else tile -= nt;
+            }
+            tail0 = max(tail0, s0 + c);
+        }
+    }
+    g.tail0 = min(tail0, n_rows);
+    if (found) return true;
+    if (tile >= ((n_rows - g.tail0 + 127) >> 7)) return false;
+    g.g0 = g.tail0; g.g1 = n_rows; g.t = tile;
+    return true;
 }
 
 // byte offset of 16-byte chunk c16 (0..7) of row r in the swizzled [64][64] bf16 image
@@ -213,6 +244,59 @@ __device__ __forceinline__ void store_rows_bf16_hilo(bf16_t* hi, bf16_t* lo, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// What a query-major workgroup (forward, dQ: 4 waves x 32 query rows) works on: its (batch, head), its rows, their key
+// interval(s) and the range of 64-key tiles it has to visit.  Three cases:
+//   * one interval per sample (r_rs == 0: encoder self-attention, cross-attention) and row-group tiles (group_tile): every row
+//     of the workgroup has the same [ks, ke) - no reductions (24 dependent ds_bpermute round trips per wave otherwise, ~8 % of
+//     a workgroup's life); a group's key tiles start at the group's first key (kbase), so only its last tile is partial;
+//   * per-row intervals: wave / workgroup extremes by reductions; rows whose interval is empty attend every key with score
+//     scale 0 (the reference's masked_fill(-finfo.max) + softmax = uniform attention).
+// `scratch`: 64 bytes of LDS.  Returns false (for the whole workgroup) when the tile does not exist.
+// ---------------------------------------------------------------------------------------------
+struct QTile { int h, b, q0, qhi, qrow, ks, ke, kbase, w_ksmax, w_kemin, kt0, kt1; bool flat; };
+__device__ __forceinline__ bool q_tile(const AttnArgs& p, char* scratch, QTile& q) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = ((p.Nq + 127) >> 7) + (p.seg ? p.n_seg + 1 : 0);
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, tiles, p.r_rs == 0 || p.seg != nullptr, pair, tile);
+    q.h = pair % p.H; q.b = pair / p.H;
+    bool uniform = p.r_rs == 0;
+    int g0 = 0;
+    q.qhi = p.Nq;
+    if (p.seg) {
+        GroupTile g;
+        if (!group_tile(p, q.b, tile, p.Nq, g)) return false;
+        g0 = g.g0; q.qhi = g.g1; tile = g.t; uniform = g.uniform;
+    } else if (tile * 128 >= p.Nq) {
+        return false;
+    }
+    q.q0 = g0 + tile * 128 + wave * 32;
+    q.qrow = min(q.q0 + (lane & 31), q.qhi - 1);
+    int ks, ke;
+    if (p.seg && uniform) { ks = g0; ke = min(q.qhi, p.Nk); }
+    else { ks = p.ks[q.b * p.r_bs + q.qrow * p.r_rs]; ke = min(p.ke[q.b * p.r_bs + q.qrow * p.r_rs], p.Nk); }
+    q.flat = ke <= ks;
+    if (q.flat) { ks = 0; ke = p.Nk; }
+    int kmin = ks, kmax = ke;
+    q.w_ksmax = ks; q.w_kemin = ke;
+    if (!uniform) {
+        const int w_lo = wave_min_i(ks), w_hi = wave_max_i(ke);
+        q.w_ksmax = wave_max_i(ks); q.w_kemin = wave_min_i(ke);
+        int* rng = (int*)scratch;
+        if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
+        __syncthreads();
+        kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
+        kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
+    }
+    q.ks = ks; q.ke = ke;
+    // (readfirstlane: these feed the scalar offsets of the LDS-DMA - as VGPR values hipcc wraps every DMA in a waterfall loop)
+    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
+    q.kbase = (p.seg && uniform) ? kmin : 0;
+    q.kt0 = (kmin - q.kbase) >> 6; q.kt1 = (kmax - q.kbase + 63) >> 6;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -221,31 +305,12 @@ constexpr float FWD_TAU = 8.f;      // the softmax reference moves when a score 
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);
-    const int h = pair % p.H, b = pair / p.H;
-    const int q0 = tile * 128 + wave * 32;
+    QTile qt;
+    if (!q_tile(p, smem + FWD_STAGES * 2 * TILE_BYTES, qt)) return;
+    const int h = qt.h, b = qt.b, q0 = qt.q0, qhi = qt.qhi, qrow = qt.qrow, ks = qt.ks, ke = qt.ke, kbase = qt.kbase;
+    const int w_ksmax = qt.w_ksmax, w_kemin = qt.w_kemin, kt0 = qt.kt0, kt1 = qt.kt1;
     const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = min(q0 + ql, p.Nq - 1);
-
-    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
-    float sc = p.scale * LOG2E;
-    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
-    // one interval per sample (encoder self-attention, cross-attention): every row of the workgroup has the same [ks, ke) -
-    // no reductions (24 dependent ds_bpermute round trips per wave otherwise, ~8 % of a workgroup's life)
-    int w_lo = ks, w_hi = ke, w_ksmax = ks, w_kemin = ke, kmin = ks, kmax = ke;
-    if (p.r_rs != 0) {
-        w_lo = wave_min_i(ks); w_hi = wave_max_i(ke);
-        w_ksmax = wave_max_i(ks); w_kemin = wave_min_i(ke);
-        int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
-        if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
-        __syncthreads();
-        kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
-        kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
-    }
-    // (readfirstlane: these feed the scalar offsets of the LDS-DMA - as VGPR values hipcc wraps every DMA in a waterfall loop)
-    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
-    const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
+    const float sc = qt.flat ? 0.f : p.scale * LOG2E;
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
     // Q is pre-scaled by scale * log2(e) (as in the backward kernels), so the scores leave the MFMA in the exp2 domain
@@ -262,8 +327,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     const DmaOff kvoff = dma_off(p.k_rs, wave, lane);               // k_rs == v_rs (checked by the launcher)
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(Kb, p.k_rs, p.Nk), vrs = slice_rsrc(Vb, p.v_rs, p.Nk);
     auto dma_tile = [&](int kt, int s) {
-        dma_tile64(krs, p.k_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES, wave);
-        dma_tile64(vrs, p.v_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
+        dma_tile64(krs, p.k_rs, kvoff, kbase + kt * 64, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(vrs, p.v_rs, kvoff, kbase + kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
     };
 
     f32x16 ot[2];
@@ -295,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
         // INITIAL accumulator of the S^T chain (the subtraction is free) and p = exp2(acc) directly; the reference only moves
         // when some score exceeds it by more than FWD_TAU (p <= 2^FWD_TAU, far from any overflow) - after the first tiles
         // that is rare.  This kernel is VALU-bound at head dim 64: 32 exp + ~48 other vector instructions per 16 MFMAs.
-        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        const bool full = (kbase + kt * 64 >= w_ksmax) && (kbase + kt * 64 + 64 <= w_kemin);
         const bool fast = full && seeded;
         const float ini = fast ? -m : 0.f;
         f32x16 st[2];
@@ -320,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
+                    const int kidx = kbase + kt * 64 + kb * 32 + acc_row(r, hh);
                     const float v = (kidx >= ks && kidx < ke) ? st[kb][r] : NEG_BIG;
                     st[kb][r] = v;
                     mx = fmaxf(mx, v);
@@ -391,7 +456,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 
     const float lt = xhalf_sum(l);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    if (q0 + ql < p.Nq) {
+    if (q0 + ql < qhi) {
         const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
         if (p.Olo) store_rows_bf16_hilo(p.O + oo, p.Olo + oo, ot, inv, hh);
         else store_rows_bf16(p.O + oo, ot, inv, hh);
@@ -411,31 +476,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_STAGES * 2 * TILE_BYTES + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);
-    const int h = pair % p.H, b = pair / p.H;
-    const int q0 = tile * 128 + wave * 32;
+    QTile qt;
+    if (!q_tile(p, smem + FWD_STAGES * 2 * TILE_BYTES, qt)) return;
+    const int h = qt.h, b = qt.b, q0 = qt.q0, qhi = qt.qhi, qrow = qt.qrow, ks = qt.ks, ke = qt.ke, kbase = qt.kbase;
+    const int w_ksmax = qt.w_ksmax, w_kemin = qt.w_kemin, kt0 = qt.kt0, kt1 = qt.kt1;
     const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = min(q0 + ql, p.Nq - 1);
-
-    int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
-    float sc = p.scale * LOG2E, gsc = p.scale;
-    if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }       // empty interval: q' = 0 -> p = exp2(-LSE2) = 1 / Nk, dQ = 0
-    // one interval per sample (encoder self-attention, cross-attention): every row of the workgroup has the same [ks, ke) -
-    // no reductions (24 dependent ds_bpermute round trips per wave otherwise, ~8 % of a workgroup's life)
-    int w_lo = ks, w_hi = ke, w_ksmax = ks, w_kemin = ke, kmin = ks, kmax = ke;
-    if (p.r_rs != 0) {
-        w_lo = wave_min_i(ks); w_hi = wave_max_i(ke);
-        w_ksmax = wave_max_i(ks); w_kemin = wave_min_i(ke);
-        int* rng = (int*)(smem + FWD_STAGES * 2 * TILE_BYTES);
-        if (lane == 0) { rng[wave] = w_lo; rng[4 + wave] = w_hi; }
-        __syncthreads();
-        kmin = min(min(rng[0], rng[1]), min(rng[2], rng[3]));
-        kmax = max(max(rng[4], rng[5]), max(rng[6], rng[7]));
-    }
-    // (readfirstlane: these feed the scalar offsets of the LDS-DMA - as VGPR values hipcc wraps every DMA in a waterfall loop)
-    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
-    const int kt0 = kmin >> 6, kt1 = (kmax + 63) >> 6;
+    // empty interval: q' = 0 -> p = exp2(-LSE2) = 1 / Nk, dQ = 0
+    const float sc = qt.flat ? 0.f : p.scale * LOG2E, gsc = qt.flat ? 0.f : p.scale;
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * 64;
     const bf16_t* Gp = p.dO + (long)b * p.do_bs + (long)qrow * p.do_rs + h * 64;
@@ -463,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
             }
         }
         delta = xhalf_sum(delta);
-        if (hh == 0 && q0 + ql < p.Nq) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = -delta;
+        if (hh == 0 && q0 + ql < qhi) p.DELTA_OUT[((long)b * p.H + h) * p.Nq + qrow] = -delta;
     }
     const float nlse2 = p.LSE[((long)b * p.H + h) * p.Nq + qrow];       // -LSE2
     f32x16 c_lse, c_del;
@@ -475,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const DmaOff kvoff = dma_off(p.k_rs, wave, lane);               // k_rs == v_rs (checked by the launcher)
     const __amdgpu_buffer_rsrc_t krs = slice_rsrc(Kb, p.k_rs, p.Nk), vrs = slice_rsrc(Vb, p.v_rs, p.Nk);
     auto dma_tile = [&](int kt, int s) {
-        dma_tile64(krs, p.k_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES, wave);
-        dma_tile64(vrs, p.v_rs, kvoff, kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
+        dma_tile64(krs, p.k_rs, kvoff, kbase + kt * 64, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(vrs, p.v_rs, kvoff, kbase + kt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
     };
 
     f32x16 dqt[2];
@@ -499,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         if (ahead) dma_tile(kt + 2, s_ >= 1 ? s_ - 1 : 2);      // that stage was last read before the previous barrier
         const char* Kt = smem + s_ * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
-        const bool full = (kt * 64 >= w_ksmax) && (kt * 64 + 64 <= w_kemin);
+        const bool full = (kbase + kt * 64 >= w_ksmax) && (kbase + kt * 64 + 64 <= w_kemin);
         f32x16 st[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -520,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = kt * 64 + kb * 32 + acc_row(r, hh);
+                    const int kidx = kbase + kt * 64 + kb * 32 + acc_row(r, hh);
                     const bool ok = (kidx >= ks && kidx < ke);
                     st[kb][r] = ok ? __builtin_amdgcn_exp2f(st[kb][r]) * dp[kb][r] : 0.f;
                 }
@@ -539,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         lds_barrier();
         s_ = (s_ == 2) ? 0 : s_ + 1;
     }
-    if (q0 + ql < p.Nq)
+    if (q0 + ql < qhi)
         store_rows_bf16(p.dQ + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * 64, dqt, gsc, hh);
 }
 
@@ -613,9 +660,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[DKV_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, (p.Nk + 127) >> 7, p.r_rs == 0, pair, tile);
+    pair_tile(blockIdx.x, p.B * p.H, ((p.Nk + 127) >> 7) + (p.seg ? p.n_seg + 1 : 0), p.r_rs == 0 || p.seg != nullptr, pair, tile);
     const int h = pair % p.H, b = pair / p.H;
-    const int kw0 = tile * 128 + wave * 32;
+    // Row-group launches (block-diagonal self-attention): the keys of a group are cut into 128-key tiles of their own; a
+    // group's workgroup sweeps (A) the group's own rows - they all see exactly the group's keys: no per-row masks except on the
+    // last, partial row tile - and then (F) the rows behind the last group ("tail": padding rows, whose per-row intervals may
+    // point anywhere) through the general path.  Tail keys are swept by tail rows only.  Samples flagged seg_bad take the
+    // per-row path below on all their rows, exactly like a launch without groups.
+    bool grouped = false;
+    int kg0 = 0, kg1 = p.Nk, tail0 = p.Nq, nA = 0;
+    if (p.seg) {
+        GroupTile g;
+        if (!group_tile(p, b, tile, p.Nk, g)) return;
+        tile = g.t;
+        grouped = !(p.seg_bad && p.seg_bad[b]);
+        if (grouped) {
+            kg0 = g.g0; kg1 = g.g1; tail0 = g.tail0;
+            nA = g.uniform ? (kg1 - kg0 + 63) >> 6 : 0;
+        }
+    } else if (tile * 128 >= p.Nk) {
+        return;
+    }
+    const int kw0 = kg0 + tile * 128 + wave * 32;
     const int kl = lane & 31, hh = lane >> 5;
     const int kidx = kw0 + kl;
     const int krow = min(kidx, p.Nk - 1);
@@ -649,11 +715,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const bool a_row = wave < 2 || per_row;                         // array indexed by the q row (else one value per sample)
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, a_row ? p.Nq * 4 : 4, 0x00020000);
     const unsigned aoff = a_row ? lane * 4 : 0;
+    // first row of the q tile with index qt of this workgroup's sweep (grouped: own rows first, then the tail rows)
+    auto tile_row = [&](int qt) { return !grouped ? qt * 64 : (qt < nA ? kg0 + qt * 64 : tail0 + (qt - nA) * 64); };
     auto load_tile = [&](int qt, int s) {
-        dma_tile64(qrs, p.q_rs, qoff, qt * 64, smem + s * 2 * TILE_BYTES, wave);
-        dma_tile64(grs, p.do_rs, goff, qt * 64, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
+        const int r0 = tile_row(qt);
+        dma_tile64(qrs, p.q_rs, qoff, r0, smem + s * 2 * TILE_BYTES, wave);
+        dma_tile64(grs, p.do_rs, goff, r0, smem + s * 2 * TILE_BYTES + TILE_BYTES, wave);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(smem + AUX_OFF + s * 1024 + wave * 256), 4,
-                                                 aoff, a_row ? qt * 256 : 0, 0, 0);
+                                                 aoff, a_row ? r0 * 4 : 0, 0, 0);
     };
 
     f32x16 dkt[2], dvt[2];
@@ -675,7 +744,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     int* agg = (int*)(smem + AGG_OFF);
     const int nq_tiles = (p.Nq + 63) >> 6;
     int u_ks = 0, u_ke = 0;                 // the sample's interval when it is uniform
-    if (!per_row) {
+    if (grouped) {
+        qt0 = 0; nqt = nA + ((p.Nq - tail0 + 63) >> 6);
+    } else if (!per_row) {
         u_ks = KSb[0]; u_ke = min(KEb[0], p.Nk);
         if (u_ke <= u_ks) { u_ks = -1; u_ke = p.Nk; }               // empty interval: uniform attention, zero score scale
         const bool touch = max(u_ks, 0) < tile * 128 + 128 && u_ke > tile * 128;
@@ -734,7 +805,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // these keys comes out as all-zero P through the general path).  Keeping the "skip" decision out of the compute
     // loop matters: with it inside, hipcc kept a second copy of the 64 dK / dV accumulators across the branch and spilled.
     int wa = nqt, wb = qt0;
-    if (!per_row) {
+    if (grouped) {
+        if (kw0 < kg1) { wa = qt0; wb = nqt; }                      // (a wave whose 32 keys lie behind the group's end idles)
+    } else if (!per_row) {
         if (u_ke > kw0 && max(u_ks, 0) < kw0 + 32) { wa = qt0; wb = nqt; }
     } else {
         for (int t0 = qt0; t0 < nqt; t0 += 64) {
@@ -777,46 +850,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     // One 32-row block.  Order of issue: [this block's 16 reads have landed] the 16 transposed reads of dO / Q | S' and dP'
     // chains (8 MFMAs; the transposed reads land under them) | exp2 / multiply / pack | the NEXT block's 16 reads | dV^T /
     // dK^T chains (8 MFMAs; the next block's reads land under them).  NQB: the next block's index inside its tile; NRF /
-    // NAUX: its fragment / constant addresses.
-#ifndef ATT_ABL
-#define ATT_ABL 0      // timing-only ablation builds (WRONG results): 1 = no exp2 / multiply / pack, 2 = LDS reads only in a wave's first tile, 4 = no MFMAs
-#endif
+    // NAUX: its fragment / constant addresses.  (The timing-only ablation branches of rounds 2 / 3 are gone from the product
+    // kernel: tools/probes/attn_bwd_dkv_ablation.md says where to find them.)
     s16x4 gfr[4][2], qfr[4][2];
 #define DKV_BLOCK(QB, NQB, NRF, NAUX)                                                                                    \
     {                                                                                                                    \
         dkv_wait(blk);                                                                                                   \
-        if (!(ATT_ABL & 2) || qt == wa) {                                                                                \
-            tr_issue<TILE_BYTES, 2 * QB>(tra, s_ * 2 * TILE_BYTES, gfr);                                                 \
-            tr_issue<0, 2 * QB>(tra, s_ * 2 * TILE_BYTES, qfr);                                                          \
-        }                                                                                                                \
+        tr_issue<TILE_BYTES, 2 * QB>(tra, s_ * 2 * TILE_BYTES, gfr);                                                     \
+        tr_issue<0, 2 * QB>(tra, s_ * 2 * TILE_BYTES, qfr);                                                              \
         f32x16 st = cat16(blk.cs), dp = cat16(blk.cd);                                                                   \
         if (cls == CLS_LANE) {           /* one interval for the whole tile: keys outside it start from -inf -> p = 0 */ \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) st[r] = lane_ok ? st[r] : -__builtin_inff();                  \
         }                                                                                                                \
-        if (!(ATT_ABL & 4)) {                                                                                            \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                             \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                             \
-            }                                                                                                            \
-        } else {                                                                                                         \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) asm volatile("" :: "v"(blk.rq[s]), "v"(blk.rg[s]));            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                  \
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rq[s], kf[s], st, 0, 0, 0);                                 \
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(blk.rg[s], vf[s], dp, 0, 0, 0);                                 \
         }                                                                                                                \
-        bf16x8 pf0, pf1, ds0, ds1;                                                                                       \
-        if (ATT_ABL & 1) {                                                                                               \
-            typedef float f32x4_ __attribute__((ext_vector_type(4)));                                                    \
-            pf0 = __builtin_bit_cast(bf16x8, f32x4_{st[0], st[1], st[2], st[3]});                                        \
-            pf1 = __builtin_bit_cast(bf16x8, f32x4_{st[4], st[5], st[6], st[7]});                                        \
-            ds0 = __builtin_bit_cast(bf16x8, f32x4_{dp[0], dp[1], dp[2], dp[3]});                                        \
-            ds1 = __builtin_bit_cast(bf16x8, f32x4_{dp[4], dp[5], dp[6], dp[7]});                                        \
-            asm volatile("" :: "v"(st), "v"(dp));                                                                        \
-        } else {                                                                                                         \
         if (cls != CLS_GENERAL) {                                                                                        \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
                 const float pe = __builtin_amdgcn_exp2f(st[r]);                                                          \
                 st[r] = pe;                                                                                              \
                 dp[r] = pe * dp[r];                                                                                      \
             }                                                                                                            \
-        } else {              /* rows with different intervals, empty intervals, rows past Nq: per-element masks */      \
+        } else {              /* rows with different intervals, empty intervals, rows past the tile's last row */        \
             const float* af = (const float*)(smem + AUX_OFF + s_ * 1024);                                                \
             const int* ai = (const int*)(af + 128);                                                                      \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
@@ -826,19 +882,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     int rks = ai[per_row ? qb0 + e : 0], rke = min(ai[64 + (per_row ? qb0 + e : 0)], p.Nk);              \
                     const bool flat = rke <= rks;                          /* empty interval: p = 1 / Nk, dS = 0 */      \
                     if (flat) { rks = 0; rke = p.Nk; }                                                                   \
-                    const bool ok = (qt * 64 + qb0 + e < p.Nq) && (kidx >= rks) && (kidx < rke);                         \
+                    const bool ok = (t_row0 + qb0 + e < t_rowhi) && (kidx >= rks) && (kidx < rke);                       \
                     const float pe = ok ? __builtin_amdgcn_exp2f(flat ? af[qb0 + e] : st[r]) : 0.f;                      \
                     st[r] = pe;                                                                                          \
                     dp[r] = flat ? 0.f : pe * dp[r];                                                                     \
                 }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
-        pf0 = pack8(st, 0); pf1 = pack8(st, 1); ds0 = pack8(dp, 0); ds1 = pack8(dp, 1);                                  \
-        }                                                                                                                \
+        const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1), ds0 = pack8(dp, 0), ds1 = pack8(dp, 1);                     \
         lgkm_wait_tied<0>(gfr);                                                                                          \
         lgkm_wait_tied<0>(qfr);                                                                                          \
-        if (!(ATT_ABL & 2) || qt == wa) dkv_issue<NQB>(blk, NRF, NAUX);                                                  \
-        if (!(ATT_ABL & 4)) {                                                                                            \
+        dkv_issue<NQB>(blk, NRF, NAUX);                                                                                  \
         _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                               \
             dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[db][0], gfr[db][1]), pf0, dvt[db], 0, 0, 0);     \
             dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[db][0], qfr[db][1]), ds0, dkt[db], 0, 0, 0);     \
@@ -847,19 +901,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(gfr[2 + db][0], gfr[2 + db][1]), pf1, dvt[db], 0, 0, 0); \
             dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(qfr[2 + db][0], qfr[2 + db][1]), ds1, dkt[db], 0, 0, 0); \
         }                                                                                                                \
-        } else {                                                                                                         \
-            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(ds0), "v"(ds1));                                                  \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4)                                                             \
-                asm volatile("" :: "v"(gfr[q4][0]), "v"(gfr[q4][1]), "v"(qfr[q4][0]), "v"(qfr[q4][1]));                  \
-        }                                                                                                                \
     }
 
     constexpr int CLS_FULL = 1, CLS_LANE = 2, CLS_GENERAL = 3;
     for (int qt = wa; qt < wb; ++qt) {
         // What this q tile is for this wave's 32 keys (scalar decisions): every row sees all of them (full); all 64 rows
         // share ONE interval (per-lane mask); anything else (per-element masks).
+        // t_ks / t_ks2 = min / max of the rows' interval starts, t_ke2 / t_ke = min / max of their ends;
+        // t_row0 / t_rowhi: the tile's first row and the end of the rows it may use
         int t_ks, t_ks2, t_ke, t_ke2;
-        if (per_row) {
+        const int t_row0 = tile_row(qt);
+        int t_rowhi = p.Nq;
+        if (grouped) {
+            // own rows: all of them see exactly [kg0, kg1) - unless the tile runs over the group's end (per-element masks:
+            // the rows behind it belong to other groups); tail rows: per-element masks
+            const bool inside = qt < nA && t_row0 + 64 <= kg1;
+            t_ks = inside ? kg0 : -1; t_ks2 = kg0; t_ke = kg1; t_ke2 = kg1;
+            if (qt < nA) t_rowhi = kg1;
+        } else if (per_row) {
             // (flat rows carry ks = -1, rows beyond Nq carry ks = INT_MAX: both force the general path)
             t_ks = __builtin_amdgcn_readfirstlane(agg[4 * qt]); t_ks2 = __builtin_amdgcn_readfirstlane(agg[4 * qt + 1]);
             t_ke2 = __builtin_amdgcn_readfirstlane(agg[4 * qt + 2]); t_ke = __builtin_amdgcn_readfirstlane(agg[4 * qt + 3]);
@@ -867,7 +926,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             const bool whole = qt * 64 + 64 <= p.Nq;
             t_ks = u_ks; t_ks2 = whole ? u_ks : INT_MAX; t_ke = u_ke; t_ke2 = whole ? u_ke : 0;
         }
-        // t_ks / t_ks2 = min / max of the rows' interval starts, t_ke2 / t_ke = min / max of their ends
         int cls;
         if (t_ks >= 0 && t_ks2 <= kw0 && t_ke2 >= kw0 + 32) cls = CLS_FULL;
         else if (t_ks >= 0 && t_ks == t_ks2 && t_ke == t_ke2) cls = CLS_LANE;
@@ -891,7 +949,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         ring_step(qt);
         s_ = (s_ + 1 == R) ? 0 : s_ + 1;
     }
-    if (kidx < p.Nk) {
+    if (kidx < kg1) {
         store_rows_bf16(p.dK + (long)b * p.dk_bs + (long)krow * p.dk_rs + h * 64, dkt, p.scale, hh);
         store_rows_bf16(p.dV + (long)b * p.dv_bs + (long)krow * p.dv_rs + h * 64, dvt, 1.f, hh);
     }
@@ -903,20 +961,64 @@ bool check(const AttnArgs& a) {
            a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0;
 }
 
+bool check_seg(const AttnArgs& a) {
+    // row groups: self-attention on one row axis, per-row intervals present for the rows outside the groups
+    return !a.seg || (a.n_seg > 0 && a.n_seg <= EGO_MAX_MODS && a.Nq == a.Nk && a.r_rs == 1 && a.r_bs == a.Nq);
+}
+
 }  // namespace
+
+extern "C" int ego_attn_fwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
+                                    const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE,
+                                    const int* ks, const int* ke, long r_bs, long r_rs, const int* seg, int n_seg, const int* seg_bad,
+                                    int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.seg = seg; a.seg_bad = seg ? seg_bad : nullptr; a.n_seg = seg ? n_seg : 0;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a) || !check_seg(a) || o_rs % 8 || o_bs % 8 || (((uintptr_t)O) & 15) || (((uintptr_t)O_lo) & 15)) return EGO_ERR_ARG;    // 16-byte output rows
+    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128 + (a.seg ? a.n_seg + 1 : 0))), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
 
 extern "C" int ego_attn_fwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
                                 const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE,
                                 const int* ks, const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk,
                                 float scale, hipStream_t stream) {
+    return ego_attn_fwd_d64_seg(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, O_lo, LSE, ks, ke, r_bs, r_rs, nullptr, 0, nullptr,
+                                B, H, Nq, Nk, scale, stream);
+}
+
+extern "C" int ego_attn_bwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
+                                    const void* V, long v_bs, long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo,
+                                    const void* dO, long do_bs, long do_rs, const float* LSE, float* DELTA,
+                                    void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
+                                    void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs,
+                                    const int* seg, int n_seg, const int* seg_bad,
+                                    int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
     AttnArgs a{};
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
     a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
-    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.seg = seg; a.seg_bad = seg ? seg_bad : nullptr; a.n_seg = seg ? n_seg : 0;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo;
+    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA; a.DELTA_OUT = DELTA;
+    a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
+    a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
+    a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a) || o_rs % 8 || o_bs % 8 || (((uintptr_t)O) & 15) || (((uintptr_t)O_lo) & 15)) return EGO_ERR_ARG;    // 16-byte output rows
-    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a);
+    if (!check(a) || !check_seg(a) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 ||
+        o_rs % 4 || o_bs % 4 || ((((uintptr_t)dQ) | ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;              // 16-byte gradient rows
+    if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
+    const int extra = a.seg ? a.n_seg + 1 : 0;
+    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128 + extra)), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128 + extra)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -927,26 +1029,7 @@ extern "C" int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void*
                                 void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                                 void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs,
                                 int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
-    AttnArgs a{};
-    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
-    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
-    a.LSE = (float*)LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
-    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
-    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo;
-    a.dO = (const bf16_t*)dO; a.do_bs = do_bs; a.do_rs = do_rs; a.DELTA = DELTA; a.DELTA_OUT = DELTA;
-    a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
-    a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
-    a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
-    if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 || o_rs % 4 || o_bs % 4 ||
-        ((((uintptr_t)dQ) | ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;                              // 16-byte gradient rows
-    if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
-#ifndef ATT_ONLY
-#define ATT_ONLY 0                      // timing builds: 1 = dQ kernel only, 2 = dK / dV kernel only
-#endif
-    if (ATT_ONLY != 2) { EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128)), dim3(256), 0, stream, a); }
-    LAUNCH_CHECK();
-    if (ATT_ONLY != 1) { EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128)), dim3(256), 0, stream, a); }
-    LAUNCH_CHECK();
-    return EGO_OK;
+    return ego_attn_bwd_d64_seg(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, O_lo, dO, do_bs, do_rs, LSE, DELTA,
+                                dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ks, ke, r_bs, r_rs, nullptr, 0, nullptr,
+                                B, H, Nq, Nk, scale, stream);
 }

@@ -30,6 +30,7 @@ struct CompactArgs {
     int* n_valid;             // [B]
     int* seg;                 // [B, n_mods, 2]  (start, count) of each slot's kept unmasked rows
     int* err;                 // [1] set if the decoder mask is not one interval per row
+    int* seg_bad;             // [B] (optional) set if a kept unmasked row's interval is not exactly its slot's segment
 };
 
 // CP_SPLIT workgroups per sample, each owning a run of 256-position groups.  A workgroup first sweeps the WHOLE
@@ -164,6 +165,9 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
                     a.ks[o] = s0;
                     a.ke[o] = min(s1, cs);
                     if (cs > nv && nv < a.n_keep) atomicOr(a.err, 1);   // a pad key would be visible: not an interval mask
+                    // the data contract's marker (masking.py:262-264) makes every target row see exactly its modality's
+                    // segment; anything else sends the sample down the attention kernels' per-row path
+                    if (unm && a.seg_bad && cs < s1) atomicOr(a.seg_bad + b, 1);
                 } else {
                     a.ks[o] = 0;
                     a.ke[o] = nv;
@@ -667,7 +671,8 @@ extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream)
     a.n_mods = d->n_mods; a.T = T; a.n_keep = d->n_keep; a.is_decoder = d->is_decoder;
     a.ids_keep = (long long*)d->ids_keep; a.pad = (unsigned char*)d->pad; a.mod_mask = (short*)d->mod_mask;
     a.slot = d->slot; a.local = d->local; a.tok = d->tok; a.ks = d->ks; a.ke = d->ke;
-    a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err;
+    a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err; a.seg_bad = d->is_decoder ? d->seg_bad : nullptr;
+    if (a.seg_bad && hipMemsetAsync(a.seg_bad, 0, (size_t)B * sizeof(int), stream) != hipSuccess) return EGO_ERR_LAUNCH;
     EGO_LAUNCH(compact_kernel, dim3(B * CP_SPLIT), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;

@@ -222,6 +222,125 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT kernel for SMALL grids (round 4): 64x64 output tile per workgroup, one tile per workgroup, 4-deep LDS-DMA ring.
+//
+// The generation path (BASELINE config 4: rgb -> depth, batch 1) runs its decoder linears on 1707 rows: a 1707 x 768
+// output is 84 tiles of 128 x 128 on a 256-CU chip, and a launch then takes as long as ONE tile - 12 to 32 K-steps, each a
+// full DMA round trip in the two-stage kernel above (24 - 65 us per launch, rocprofv3: profiles/r04_eval_rgb2depth_*).
+// Such a launch is bound by the latency of one workgroup's K loop, not by MFMA or HBM rate, so this kernel (a) cuts the
+// output into 64 x 64 tiles - four times the workgroups, a quarter of the work each - and (b) keeps three K-steps in
+// flight (counted vmcnt, one barrier per step), so that a step costs its LDS reads + 8 MFMAs per wave rather than a DMA
+// round trip.  Same operand layout and swizzle as gemm_nt_kernel (64-row images); epilogues straight from the accumulator
+// registers (a lane owns 4 consecutive output columns: 8- / 16-byte stores), bit-identical results to the other NT kernels
+// up to the fp32 summation order inside the MFMA chain (same K order: identical here).
+// ---------------------------------------------------------------------------------------------
+constexpr int S64_STAGES = 4;
+constexpr int S64_TILE = 64 * 128;                 // one operand tile: 64 rows x 64 bf16 = 8 KiB
+constexpr int S64_STAGE = 2 * S64_TILE;            // A + B
+constexpr int NT64_LDS = S64_STAGES * S64_STAGE;   // 64 KiB: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int M = p.M;
+    long moff = 0;
+    if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
+    const int tiles_n = (p.N + 63) >> 6;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (tile / tiles_n) * 64, col0 = (tile % tiles_n) * 64;
+    if (row0 >= M) return;
+    const int nt = p.K / BK;
+
+    // staging: wave instruction (2 * wave + j) of either operand writes tile rows 8 (2 wave + j) .. +7 (1 KiB, lane-linear);
+    // slot s of row r holds global chunk s ^ (r & 7).  Rows beyond M / N are clamped (they feed outputs that are never stored).
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (2 * wave + j) + (lane >> 3);
+        const int c = ((lane & 7) ^ (r & 7)) * 8;
+        ga[j] = p.A + (moff + min(row0 + r, M - 1)) * p.lda + c;
+        gb[j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + c;
+    }
+    auto stage = [&](int s, int k0) {
+        char* sa = smem + s * S64_STAGE + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(ga[j] + k0, sa + j * 1024);
+            glds16(gb[j] + k0, sa + S64_TILE + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < S64_STAGES - 1; ++s)
+        if (s < nt) stage(s, s * BK);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        // K-step kt must have landed; the (at most two) younger steps in flight stay out: 4 DMA instructions per wave and step
+        const int younger = min(nt - 1 - kt, S64_STAGES - 2);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                   // ... for every wave; and every wave is done reading step kt - 1
+        if (kt + S64_STAGES - 1 < nt) stage(cur == 0 ? S64_STAGES - 1 : cur - 1, (kt + S64_STAGES - 1) * BK);
+        const char* sa = smem + cur * S64_STAGE;
+        const char* sb = sa + S64_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+            const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ar = wm * 32 + i * 16 + (lane & 15);
+                af[i] = *(const bf16x8*)(sa + ar * 128 + ((c ^ (ar & 7)) << 4));
+                const int br = wn * 32 + i * 16 + (lane & 15);
+                bfr[i] = *(const bf16x8*)(sb + br * 128 + ((c ^ (br & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    // operands swapped: D[row = n (4 regs)][col = m (lane & 15)]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        cur = (cur + 1 == S64_STAGES) ? 0 : cur + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gm = row0 + wm * 32 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = col0 + wn * 32 + j * 16 + 4 * (lane >> 4);
+            if (gm >= M || gn >= p.N) continue;
+            const long mrow = moff + gm;
+            f32x4 v = acc[i][j];
+            if (p.epi == EGO_EPI_BF16) {
+                *(u32x2*)((bf16_t*)p.C + mrow * p.ldc + gn) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                continue;
+            }
+            if (p.epi == EGO_EPI_RESID) {
+                const f32x4 rr = *(const f32x4*)(p.R + mrow * p.ldr + gn);
+                v = f32x4{rr[0] + round_bf16(v[0]), rr[1] + round_bf16(v[1]), rr[2] + round_bf16(v[2]), rr[3] + round_bf16(v[3])};
+            } else if (p.epi == EGO_EPI_BIAS_RESID) {
+                const f32x4 rr = *(const f32x4*)(p.R + mrow * p.ldr + gn);
+                const f32x4 b = *(const f32x4*)(p.bias + gn);
+                v = f32x4{rr[0] + round_bf16(v[0] + round_bf16(b[0])), rr[1] + round_bf16(v[1] + round_bf16(b[1])),
+                          rr[2] + round_bf16(v[2] + round_bf16(b[2])), rr[3] + round_bf16(v[3] + round_bf16(b[3]))};
+            }
+            *(f32x4*)((float*)p.C + mrow * p.ldc + gn) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NT kernel, 256x256 tile, 8 waves, staggered half-phases (for the large GEMMs).
 //
 // Waves 0-3 (group 0, output rows 0-127) and 4-7 (group 1, rows 128-255) share the four SIMDs pairwise
@@ -1121,10 +1240,12 @@ constexpr long TN256_MIN_AREA = 512L * 1024L;     // smallest Ni*Nj sent to the 
 // 1 = by shape, 0 = 128x128 kernels only, 2 = 256x256 wherever legal) and the one-time "LDS attributes set" latch.
 int g_nt256 = 1;
 int g_tn256 = 1;
+int g_nt64_tiles = 400;      // NT launches of at most this many 128x128 tiles run on 64x64 tiles instead (0 = never; ego_gemm_small_tiles)
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT64_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
@@ -1154,6 +1275,15 @@ extern "C" int ego_gemm_kernel_mode(int nt256, int tn256) {
     return EGO_OK;
 }
 
+extern "C" int ego_gemm_small_tiles(int max_tiles128) {
+    // tuning / test hook like ego_gemm_kernel_mode: NT launches of at most `max_tiles128` 128x128 tiles use the 64x64-tile
+    // small-grid kernel (0 = never).  Returns the previous value.
+    if (max_tiles128 < 0) return g_nt64_tiles;
+    const int old = g_nt64_tiles;
+    g_nt64_tiles = max_tiles128;
+    return old;
+}
+
 extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                                 const float* R, long ldr, const float* bias, const int* m_range,
                                 int M, int N, int K, int epi, hipStream_t stream) {
@@ -1180,6 +1310,14 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
         return EGO_OK;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // under-filled grids (the generation path's 1707-row linears): 64x64 tiles, four times the workgroups (gemm_nt64_kernel).
+    // With a device-side row range the host M is only an upper bound: the grid is sized for it, surplus workgroups exit.
+    if (g_nt64_tiles > 0 && tiles <= g_nt64_tiles) {
+        const int tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+        EGO_LAUNCH(gemm_nt64_kernel, dim3(tiles64), dim3(256), NT64_LDS, stream, a);
+        LAUNCH_CHECK();
+        return EGO_OK;
+    }
     EGO_LAUNCH(gemm_nt_kernel, dim3(tiles < NT_WGS ? tiles : NT_WGS), dim3(256), NT_LDS, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void cast_w_kernel(const float* __restrict__ W
 // ---------------------------------------------------------------------------------------------
 // cross-entropy over bf16 logits rows [row_off, row_off + n) of a [*, V] buffer (ld = V).
 // fwd: nll[row] = lse - logit[target]; lse[row] kept.  bwd (in place): logits <- (softmax - onehot) * coef,
-// coef = *gscale / (n_mods * n).  One workgroup per row.
+// coef = *gscale / (n_mods * n) (loss_type 'mod'), or *gscale * lw[0] / n with the modality's loss weight lw (ego_loss_weights:
+// 'weighted_mod' / 'token').  One workgroup per row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ logits, long ld, int V,
                                                      const int* __restrict__ targets, const int* __restrict__ range,
@@ -329,14 +330,14 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V,
                                                      const int* __restrict__ targets, const int* __restrict__ range,
                                                      const float* __restrict__ lse_in, const float* __restrict__ gscale,
-                                                     float inv_mods) {
+                                                     float inv_mods, const float* __restrict__ lw) {
     const int off = range[0], n = range[1];
     const int r = blockIdx.x;
     if (r >= n) return;
     const long row = (long)off + r;
     bf16_t* lr = logits + row * ld;
     const float lse = lse_in[row];
-    const float coef = gscale[0] * inv_mods / (float)n;
+    const float coef = gscale[0] * (lw ? lw[0] : inv_mods) / (float)n;
     const int tgt = targets[row];
     const int vc = V >> 3;
     for (int c = threadIdx.x; c < vc; c += 256) {
@@ -362,7 +363,8 @@ template <int NCH>
 __global__ __launch_bounds__(256, 2) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V,
                                                          const int* __restrict__ targets, const int* __restrict__ range,
                                                          float* __restrict__ lse_out, float* __restrict__ nll_out,
-                                                         const float* __restrict__ gscale, float inv_mods) {
+                                                         const float* __restrict__ gscale, float inv_mods,
+                                                         const float* __restrict__ lw) {
     __shared__ float red[9];
     const int off = range[0], n = range[1];
     const int r = blockIdx.x;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void ce_fwd_bwd_kernel(bf16_t* __restrict__
     }
     __syncthreads();                         // (also orders thread 0's read of the target logit before the stores below)
     const float lse = red[8];
-    const float coef = gscale[0] * inv_mods / (float)n;
+    const float coef = gscale[0] * (lw ? lw[0] : inv_mods) / (float)n;
     // (the row stays PACKED across the barrier: without this hipcc keeps the first phase's 8 floats per chunk alive too)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(a[j]));
@@ -434,8 +436,11 @@ __global__ __launch_bounds__(256, 2) void ce_fwd_bwd_kernel(bf16_t* __restrict__
 // micro-batch (256 KB) are four round trips, and the sum order is fixed (bitwise reproducible).  `err` (optional): the
 // compaction's "decoder mask is not an interval" flag - a set flag poisons the loss (NaN: the train loop's non-finite
 // check then stops the run like the reference's, run_training_egom2p.py:731-734) and is cleared for the next step.
+// lw / ms (optional, ego_loss_weights): loss = sum_m lw[m] * mean_nll[m] and the reported mod_loss[m] = ms[m] * mean_nll[m]
+// (forward_weighted_mod_loss / forward_token_loss, egom2p_model.py:583-612, 646-681).
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ nll, const int* __restrict__ ranges,
-                                                             int n_mods, float* __restrict__ out, int* __restrict__ err) {
+                                                             int n_mods, float* __restrict__ out, int* __restrict__ err,
+                                                             const float* __restrict__ lw, const float* __restrict__ ms) {
     __shared__ float red[16];
     const int tid = threadIdx.x;
     float total = 0.f;
@@ -464,11 +469,11 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __rest
 #pragma unroll
         for (int w = 0; w < 16; ++w) r += red[w];
         const float ml = n > 0 ? r / (float)n : 0.f;
-        if (tid == 0) out[1 + m] = ml;
-        total += ml;
+        if (tid == 0) out[1 + m] = ms ? ms[m] * ml : ml;
+        total += lw ? lw[m] * ml : ml;
     }
     if (tid == 0) {
-        float v = total / (float)n_mods;
+        float v = lw ? total : total / (float)n_mods;
         if (err && *err) {
             v = __int_as_float(0x7fc00000);
             for (int m = 0; m < n_mods; ++m) out[1 + m] = v;
@@ -653,30 +658,63 @@ extern "C" int ego_ce_fwd(const void* logits, long ld, int V, const int* targets
 }
 
 extern "C" int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows,
-                          const float* lse, const float* gscale, int n_mods, hipStream_t stream) {
+                          const float* lse, const float* gscale, int n_mods, const float* loss_w, hipStream_t stream) {
     if (max_rows <= 0) return EGO_OK;
     if (V % 8 || ld % 8 || n_mods <= 0) return EGO_ERR_ARG;
-    EGO_LAUNCH(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods);
+    EGO_LAUNCH(ce_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, gscale, 1.f / n_mods, loss_w);
     LAUNCH_CHECK();
     return EGO_OK;
 }
 
 extern "C" int ego_ce_fwd_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse,
-                              float* nll, const float* gscale, int n_mods, hipStream_t stream) {
+                              float* nll, const float* gscale, int n_mods, const float* loss_w, hipStream_t stream) {
     if (max_rows <= 0) return EGO_OK;
     if (V % 8 || ld % 8 || n_mods <= 0 || V > 65536) return EGO_ERR_ARG;      // a row must fit the registers of one workgroup
     if (V <= 2048) {
-        EGO_LAUNCH(ce_fwd_bwd_kernel<1>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods);
+        EGO_LAUNCH(ce_fwd_bwd_kernel<1>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods, loss_w);
     } else {
-        EGO_LAUNCH(ce_fwd_bwd_kernel<32>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods);
+        EGO_LAUNCH(ce_fwd_bwd_kernel<32>, dim3(max_rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, targets, range, lse, nll, gscale, 1.f / n_mods, loss_w);
     }
     LAUNCH_CHECK();
     return EGO_OK;
 }
 
-extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, hipStream_t stream) {
+extern "C" int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, const float* loss_w,
+                                 const float* mod_scale, hipStream_t stream) {
     if (n_mods <= 0 || n_mods > EGO_MAX_MODS) return EGO_ERR_ARG;
-    EGO_LAUNCH(loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, nll, ranges, n_mods, out, err);
+    EGO_LAUNCH(loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, nll, ranges, n_mods, out, err, loss_w, mod_scale);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+namespace {
+struct LossWArgs { const int* ranges; int n_mods, mode; int vocab[EGO_MAX_MODS]; float* lw; float* ms; };
+// one thread: the loss weights of `weighted_mod` (mode 1) and `token` (mode 2) from the per-modality row counts of this batch
+__global__ void loss_weights_kernel(LossWArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float tot = 0.f;
+    for (int m = 0; m < a.n_mods; ++m) tot += (float)a.ranges[2 * m + 1] * (float)a.vocab[m];      // logits.numel() per modality
+    for (int m = 0; m < a.n_mods; ++m) {
+        if (a.mode == 1) {
+            // loss / math.log(vocab_size) * 5.545177444479562 (= ln 256: "set 256 as default codebook size"), then the mean over modalities
+            const float sc = 5.545177444479562f / logf((float)a.vocab[m]);
+            a.ms[m] = sc;
+            a.lw[m] = sc / (float)a.n_mods;
+        } else {
+            // sum(mod_loss * mod_count) / sum(mod_count), mod_count = logits.numel() = rows x vocab (0 / 0 = NaN like the reference)
+            a.ms[m] = 1.f;
+            a.lw[m] = (float)a.ranges[2 * m + 1] * (float)a.vocab[m] / tot;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ego_loss_weights(const int* ranges, const int* vocab, int n_mods, int mode, float* loss_w, float* mod_scale,
+                                hipStream_t stream) {
+    if (n_mods <= 0 || n_mods > EGO_MAX_MODS || (mode != 1 && mode != 2) || !ranges || !vocab || !loss_w || !mod_scale) return EGO_ERR_ARG;
+    LossWArgs a{ranges, n_mods, mode, {0}, loss_w, mod_scale};
+    for (int m = 0; m < n_mods; ++m) { if (vocab[m] < 2) return EGO_ERR_ARG; a.vocab[m] = vocab[m]; }
+    EGO_LAUNCH(loss_weights_kernel, dim3(1), dim3(64), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -5,14 +5,20 @@
 // `top_k_top_p_filtering` (:332-359, a full descending sort + cumsum + argsort + gather over V = 64000),
 // `softmax(filtered / temperature)` and `torch.multinomial` (:361-371).
 //
-// One 1024-thread workgroup per row keeps the whole row in registers (<= 64 logits per lane):
-//   * nucleus set without sorting: token j is kept iff the probability mass of strictly larger logits
-//     is <= top_p (the reference keeps sorted tokens while the cumulative mass *before* them is <= top_p);
-//     the cut is found by a 32-step binary search on the order-preserving integer image of the logits.
-//     Tokens with exactly equal logits are kept or dropped together (the reference's sort breaks such
-//     ties arbitrarily) - the only semantic difference.
-//   * sample by inverse CDF of softmax(kept / T) with a caller-supplied uniform number per row
-//     (explicit RNG, so a captured graph replays deterministically).
+// One 1024-thread workgroup per row.  The row (2 x 128 KB of bf16 logits at V = 64000) is read three times - the first
+// time from HBM, then from L2 - by 16-byte loads, so that only ONE float per token has to live in registers (64 per lane):
+//   pass 1  mixed logit -> row maximum and arg-max;
+//   pass 2  p = exp(mixed - max) kept in registers -> Z, then the nucleus cut WITHOUT sorting: token j is kept iff the
+//           probability mass of strictly larger tokens is <= top_p (the reference keeps sorted tokens while the cumulative
+//           mass *before* them is <= top_p); the cut is a <= 30-step binary search on the bit pattern of p (p >= 0: the
+//           integer order of the bits is the order of the values) whose step costs compare / select / add per token - no
+//           exponential inside the search (round 3 recomputed exp() for all 64 tokens of a lane in each of 32 steps and
+//           searched on the logit: 2.0 ms per 1707-row launch, 13 % of a rgb -> depth clip at batch 1).  Tokens whose p is
+//           equal (equal logits, or logits closer than one fp32 ulp of p) are kept or dropped together - the reference's
+//           sort breaks such ties arbitrarily: the only semantic difference;
+//   pass 3  q = exp((mixed - max) / T) of the kept tokens overwrites p; the sample is the inverse CDF of q at a
+//           caller-supplied uniform number per row (explicit RNG, so a captured graph replays deterministically).
+// Element order of the CDF: lane-major (lane t owns chunks t, t + 1024, ... of 8 consecutive tokens).
 #include "common.h"
 #include "egom2p_hip.h"
 
@@ -48,6 +54,43 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+// slot k = 8 m + e of lane t is token 8 (t + 1024 m) + e (VEC: rows 16-byte aligned, V % 8 == 0) or token t + 1024 k
+template <bool VEC>
+__device__ __forceinline__ int slot_token(int tid, int k) { return VEC ? 8 * (tid + SMP_THREADS * (k >> 3)) + (k & 7) : tid + SMP_THREADS * k; }
+
+// mixed logits of chunk m (slots 8m .. 8m+7) of this lane; tokens beyond V come out as -3e38.  Branch-free: a chunk beyond V
+// loads the row's last chunk and is overwritten afterwards (divergent branches around the loads cost hipcc ~300 spilled SGPRs).
+template <bool VEC, bool CFG>
+__device__ __forceinline__ void load_chunk(const bf16_t* __restrict__ c, const bf16_t* __restrict__ u, int V, float cfg, int tid, int m,
+                                           float (&v)[8]) {
+    if (VEC) {
+        const int i0 = 8 * (tid + SMP_THREADS * m);
+        const int j0 = min(i0, V - 8);
+        const u32x4 cw = *(const u32x4*)(c + j0);
+        u32x4 uw = {0u, 0u, 0u, 0u};
+        if (CFG) uw = *(const u32x4*)(u + j0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cv = __uint_as_float((e & 1) ? (cw[e >> 1] & 0xffff0000u) : (cw[e >> 1] << 16));
+            const float uv = __uint_as_float((e & 1) ? (uw[e >> 1] & 0xffff0000u) : (uw[e >> 1] << 16));
+            // explicit roundings (no fma contraction): bit-identical to torch's uncond + (cond - uncond) * s
+            const float x = CFG ? __fadd_rn(uv, __fmul_rn(__fsub_rn(cv, uv), cfg)) : cv;
+            v[e] = (i0 < V) ? x : -3.0e38f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = tid + SMP_THREADS * (8 * m + e);
+            const int j = min(i, V - 1);
+            const float cv = bf16_to_f32(c[j]);
+            const float uv = CFG ? bf16_to_f32(u[j]) : 0.f;
+            const float x = CFG ? __fadd_rn(uv, __fmul_rn(__fsub_rn(cv, uv), cfg)) : cv;
+            v[e] = (i < V) ? x : -3.0e38f;
+        }
+    }
+}
+
+template <bool VEC, bool CFG>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __restrict__ cond, const bf16_t* __restrict__ uncond,
                                                              long ld, int V, float cfg, float top_p, float temperature,
                                                              const float* __restrict__ uniforms, int* __restrict__ out_tok,
@@ -58,33 +101,26 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
     const long row = blockIdx.x;
     const int tid = threadIdx.x;
     const bf16_t* c = cond + row * ld;
-    const bf16_t* u = uncond ? uncond + row * ld : nullptr;
+    const bf16_t* u = CFG ? uncond + row * ld : nullptr;
 
-    float l[SMP_MAXE];
+    // ---- pass 1: maximum and arg-max (lowest index among equal maxima: the answer at temperature 0, the fallback below)
     float mx = -3.0e38f;
+    int best = 0x7fffffff;
 #pragma unroll
-    for (int k = 0; k < SMP_MAXE; ++k) {
-        const int i = tid + SMP_THREADS * k;
-        float v = -3.0e38f;
-        if (i < V) {
-            const float cv = bf16_to_f32(c[i]);
-            // explicit roundings (no fma contraction): bit-identical to torch's uncond + (cond - uncond) * s
-            v = u ? __fadd_rn(bf16_to_f32(u[i]), __fmul_rn(__fsub_rn(cv, bf16_to_f32(u[i])), cfg)) : cv;
-            mx = fmaxf(mx, v);
+    for (int m = 0; m < SMP_MAXE / 8; ++m) {
+        float v[8];
+        load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // (slots are visited in increasing token order: strict > keeps the lowest index; a slot beyond V holds -3e38)
+            if (v[e] > mx) { mx = v[e]; best = slot_token<VEC>(tid, 8 * m + e); }
         }
-        l[k] = v;
     }
+    const float lane_mx = mx;
     mx = block_max(mx, red);
-
-    // arg-max (lowest index among equal maxima): the answer at temperature 0 and the fallback below
     int amax;
     {
-        int best = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < SMP_MAXE; ++k) {
-            const int i = tid + SMP_THREADS * k;
-            if (i < V && l[k] == mx) best = min(best, i);
-        }
+        best = (lane_mx == mx) ? best : 0x7fffffff;
         best = wave_min_i(best);
         __syncthreads();
         if ((tid & 63) == 0) ((int*)red)[tid >> 6] = best;
@@ -99,36 +135,53 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
         return;
     }
 
-    // ---- nucleus cut: smallest key K with mass{key > K} <= top_p * Z
+    // ---- pass 2: p = exp(mixed - max) (0 beyond V) and the nucleus cut: smallest bit pattern K with mass{p > K} <= top_p * Z
+    float p[SMP_MAXE];
     unsigned cut = 0u;                       // keep everything
     if (top_p > 0.f) {
         float z = 0.f;
 #pragma unroll
-        for (int k = 0; k < SMP_MAXE; ++k) z += (tid + SMP_THREADS * k < V) ? __expf(l[k] - mx) : 0.f;
+        for (int m = 0; m < SMP_MAXE / 8; ++m) {
+            float v[8];
+            load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[8 * m + e] = __expf(v[e] - mx);              // a slot beyond V: exp(-3e38 - max) = 0
+                z += p[8 * m + e];
+            }
+        }
         z = block_sum(z, red);
         const float budget = top_p * z;
-        unsigned lo = 0u, hi = f2key(mx);    // invariant: mass{> hi} <= budget ; answer in [lo, hi]
-        for (int it = 0; it < 32 && lo < hi; ++it) {
+        unsigned lo = 0u, hi = __float_as_uint(1.0f);    // invariant: mass{p > hi} <= budget ; answer in [lo, hi]
+        while (lo < hi) {
             const unsigned mid = lo + ((hi - lo) >> 1);
-            float s = 0.f;
+            const float t = __uint_as_float(mid);
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < SMP_MAXE; ++k)
-                s += (tid + SMP_THREADS * k < V && f2key(l[k]) > mid) ? __expf(l[k] - mx) : 0.f;
-            s = block_sum(s, red);
+            for (int k = 0; k < SMP_MAXE; k += 2) {
+                s0 += (p[k] > t) ? p[k] : 0.f;
+                s1 += (p[k + 1] > t) ? p[k + 1] : 0.f;
+            }
+            const float s = block_sum(s0 + s1, red);
             if (s <= budget) hi = mid; else lo = mid + 1;
         }
         cut = hi;
     }
 
-    // ---- sample from softmax(kept / T) by inverse CDF (thread-major element order)
+    // ---- pass 3: q = exp((mixed - max) / T) of the kept tokens (in p's registers); sample by inverse CDF, lane-major order
     const float invT = 1.f / temperature;
-    float q[SMP_MAXE];
     float mine = 0.f;
 #pragma unroll
-    for (int k = 0; k < SMP_MAXE; ++k) {
-        const bool keep = (tid + SMP_THREADS * k < V) && f2key(l[k]) >= cut;
-        q[k] = keep ? __expf((l[k] - mx) * invT) : 0.f;
-        mine += q[k];
+    for (int m = 0; m < SMP_MAXE / 8; ++m) {
+        float v[8];
+        load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * m + e;
+            const bool keep = cut == 0u || __float_as_uint(p[k]) >= cut;      // (a slot beyond V: q = exp(-inf) = 0 either way)
+            p[k] = keep ? __expf((v[e] - mx) * invT) : 0.f;
+            mine += p[k];
+        }
     }
     // inclusive scan of per-thread masses
     float incl = mine;
@@ -157,14 +210,14 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
         float pq = 0.f;
 #pragma unroll
         for (int k = 0; k < SMP_MAXE; ++k) {
-            if (pick < 0 && q[k] > 0.f) {
-                run += q[k];
-                if (target < run || k == SMP_MAXE - 1) { pick = tid + SMP_THREADS * k; pq = q[k]; }
+            if (pick < 0 && p[k] > 0.f) {
+                run += p[k];
+                if (target < run || k == SMP_MAXE - 1) { pick = slot_token<VEC>(tid, k); pq = p[k]; }
             }
         }
         if (pick < 0) {                       // numerical edge: take this thread's last kept element
 #pragma unroll
-            for (int k = 0; k < SMP_MAXE; ++k) if (q[k] > 0.f) { pick = tid + SMP_THREADS * k; pq = q[k]; }
+            for (int k = 0; k < SMP_MAXE; ++k) if (p[k] > 0.f) { pick = slot_token<VEC>(tid, k); pq = p[k]; }
         }
         if (atomicCAS(&s_pick[0], -1, pick) == -1) s_pick[1] = __float_as_int(pq / total);
     }
@@ -184,8 +237,15 @@ extern "C" int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld
                                    hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
     if (V <= 0 || V > SMP_THREADS * SMP_MAXE || !cond || !uniforms || !out_tokens) return EGO_ERR_ARG;
-    EGO_LAUNCH(sample_kernel, dim3(rows), dim3(SMP_THREADS), 0, stream, (const bf16_t*)cond, (const bf16_t*)uncond, ld, V,
-               cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob);
+    const bool vec = V % 8 == 0 && V >= 8 && ld % 8 == 0 && ((((uintptr_t)cond) | ((uintptr_t)uncond)) & 15) == 0;
+#define SMP_GO(VEC, CFG)                                                                                                         \
+    EGO_LAUNCH((sample_kernel<VEC, CFG>), dim3(rows), dim3(SMP_THREADS), 0, stream, (const bf16_t*)cond, (const bf16_t*)uncond, ld, V, \
+               cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob)
+    if (vec && uncond) { SMP_GO(true, true); }
+    else if (vec) { SMP_GO(true, false); }
+    else if (uncond) { SMP_GO(false, true); }
+    else { SMP_GO(false, false); }
+#undef SMP_GO
     LAUNCH_CHECK();
     return EGO_OK;
 }

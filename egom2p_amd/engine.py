@@ -104,6 +104,8 @@ class Engine:
         # kernels fight for LDS / L2), so it is off by default (EGOM2P_WGRAD_STREAM=1 enables it).
         import os
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("EGOM2P_WGRAD_STREAM", "0") == "1" else None
+        # decoder self-attention launched by row groups (one interval per workgroup); 0: per-row interval launches (round 3)
+        self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
 
     def _ring_next(self):
         self._ring_i = (self._ring_i + 1) % len(self.ring_b)
@@ -414,7 +416,8 @@ class Engine:
             return dict(ids_keep=e(B, n_keep, dt=torch.int64), pad=e(B, n_keep, dt=torch.uint8),
                         mod_mask=e(B, n_keep, dt=torch.int16), slot=e(B, n_keep, dt=I32), local=e(B, n_keep, dt=I32),
                         tok=e(B, n_keep, dt=I32), ks=e(B, n_keep, dt=I32), ke=e(B, n_keep, dt=I32),
-                        n_valid=e(B, dt=I32), seg=e(B, self.n_mods, 2, dt=I32), err=torch.zeros(1, device=dev, dtype=I32))
+                        n_valid=e(B, dt=I32), seg=e(B, self.n_mods, 2, dt=I32), err=torch.zeros(1, device=dev, dtype=I32),
+                        seg_bad=torch.zeros(B, device=dev, dtype=I32))
 
         self.ce, self.cd = side(N, RN), side(M, RM)
         self.zero_b = torch.zeros(B, device=dev, dtype=I32)
@@ -453,6 +456,8 @@ class Engine:
         self.lse_ce = e(RM, dt=F32)
         self.nll = torch.zeros(RM, device=dev, dtype=F32)
         self.loss_out = torch.zeros(1 + self.n_mods, device=dev, dtype=F32)
+        self.loss_w = torch.zeros(self.n_mods, device=dev, dtype=F32)      # loss_type 'weighted_mod' / 'token': per-modality weights
+        self.loss_ms = torch.ones(self.n_mods, device=dev, dtype=F32)
         # backward temporaries
         R = max(RN, RM)
         self.dres = e(RM, D, dt=F32)               # decoder residual-stream gradient
@@ -553,30 +558,44 @@ class Engine:
                 self.side.wait_event(ev)
                 run()
 
-    def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk, o_lo=None):
+    def _attn(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, lse, ks, ke, r_bs, r_rs, B, Nq, Nk, o_lo=None, seg=None, seg_bad=None):
         A = self.A
         ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, lse, ks, ke, r_bs, r_rs,
-                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP)
+                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP,
+                     seg=seg, seg_bad=seg_bad)
+
+    def _dec_groups(self):
+        """Row groups of the decoder's block-diagonal self-attention mask for the attention kernels (head dim 64): the
+        compaction's (start, count) per modality slot + its per-sample "not the contract's mask" flags.  With them every
+        attention workgroup sees one interval; EGOM2P_ATTN_GROUPS=0 keeps the per-row launches."""
+        if self.HDP != 64 or not self.attn_groups:
+            return {}
+        return dict(seg=self.cd["seg"][:self.B], seg_bad=self.cd["seg_bad"][:self.B])
 
     def _attn_bwd(self, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, do_t, lse, dq_t, dkv_t, ks, ke, r_bs, r_rs, B, Nq, Nk,
-                  o_lo=None):
+                  o_lo=None, seg=None, seg_bad=None):
         A = self.A
         ops.attn_bwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, do_t.data_ptr(), Nq * A, A,
                      lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
                      kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale,
-                     o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP)
+                     o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP, seg=seg, seg_bad=seg_bad)
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,
-                need_loss: bool = True, group_rows: bool = True, loss_grad=None):
+                need_loss: bool = True, group_rows: bool = True, loss_grad=None, loss_type: str = "mod"):
         """Forward of one micro-batch (tensors already on the device).  Returns (loss, {mod: loss}) as
         views of a device buffer: reading them is the only host sync.
         loss_grad (float or 1-element device tensor, optional): the upstream d loss the following `backward` will be
         called with.  A training step knows it when the loss is formed, and the cross-entropy then runs forward and
         backward in ONE pass over the logits (`ego_ce_fwd_bwd`: bitwise the two-call result, the 16.5 GB of logits of a
-        64-clip micro-batch are read once instead of twice); `backward` must then be given the same value."""
+        64-clip micro-batch are read once instead of twice); `backward` must then be given the same value.
+        loss_type: 'mod' (forward_mod_loss, egom2p_model.py:614-644), 'weighted_mod' (:583-612) or 'token' (:646-681); the two
+        others weight the modalities' mean cross-entropies by device-side weights (`ego_loss_weights`), forward and backward."""
+        if loss_type not in ops.LOSS_MODES:
+            raise ValueError("Invalid loss type")                  # the reference's message (egom2p_model.py:579)
+        self._loss_mode = ops.LOSS_MODES[loss_type]
         if self.weights_dirty:
             self.refresh_weights()
         cfg, D, A, Fp, N, M = self.cfg, self.D, self.A, self.Fp, self.N, self.M
@@ -642,7 +661,7 @@ class Engine:
             self._ln(w["x"][:RM], f"{pre}.norm1.weight", w["ln1"], w["st1"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln1"], w["qkv"], RM)
             self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], cd["ks"], cd["ke"], M, 1, B, M, M,
-                       o_lo=w["ao_lo"])
+                       o_lo=w["ao_lo"], **self._dec_groups())
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
             self._ln(w["x1"][:RM], f"{pre}.query_norm.weight", w["qn"], w["stq"])
             self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
@@ -665,6 +684,10 @@ class Engine:
         self._ce_done, self._ce_grad = set(), loss_grad
         if loss_grad is not None:
             self._set_gscale(loss_grad)
+        lw = ms = None
+        if self._loss_mode:
+            lw, ms = self.loss_w, self.loss_ms
+            ops.loss_weights(self.ranges, [m.vocab_size for m in mods], self._loss_mode, lw, ms)
         for c, m in enumerate(mods):
             l = self.lin[self.logit_key[m.name]]
             ub = min(RM, B * m.max_tokens)
@@ -672,12 +695,12 @@ class Engine:
             ops.gemm_nt(self.yn, l.wb, lg, ub, m.vocab_size, D, L.EPI_BF16, m_range=self.ranges[c], lda=D, ldb=D, ldc=m.vocab_size)
             if loss_grad is not None and ops.ce_fusable(m.vocab_size):
                 ops.ce_fwd_bwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll, self.gscale,
-                               self.n_mods)
+                               self.n_mods, loss_w=None if lw is None else lw[c:c + 1])
                 self._ce_done.add(c)
             else:
                 ops.ce_fwd(lg, m.vocab_size, m.vocab_size, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.nll)
         # a decoder_attention_mask that is not one interval per row (compaction flag) turns the loss into NaN
-        ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out, err=cd["err"])
+        ops.loss_finalize(self.nll, self.ranges, self.n_mods, self.loss_out, err=cd["err"], loss_w=lw, mod_scale=ms)
         return self.loss_out[0], {m.name: self.loss_out[1 + c] for c, m in enumerate(mods)}
 
     # ------------------------------------------------------------------------------------ backward
@@ -699,13 +722,13 @@ class Engine:
                           dx_in=dres, dx_bf16=nb, width=self.Dl)
         return nb
 
-    def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke, r_bs=None, r_rs=1):
+    def _self_attn_bwd(self, pre, attn_name, w, dres, dres_b, rows, Nq, ks, ke, r_bs=None, r_rs=1, groups=None):
         A, B = self.A, self.B
         r_bs = Nq if r_bs is None else r_bs
         dao, dqkv, dln = self.t_a, self.t_3d, self.t_d2
         self._lin_bwd(f"{pre}.{attn_name}.proj.weight", dres_b, w["ao"], dao, rows)
         self._attn_bwd(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], dao, w["lse"], dqkv, dqkv, ks, ke, r_bs, r_rs, B, Nq, Nq,
-                       o_lo=w["ao_lo"])
+                       o_lo=w["ao_lo"], **(groups or {}))
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
         nb = self._ring_next()
         ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
@@ -749,7 +772,8 @@ class Engine:
             V = m.vocab_size
             lg = self.logits[V]
             if c not in self._ce_done:
-                ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods)
+                ops.ce_bwd(lg, V, V, self.tgt_perm, self.ranges[c], ub, self.lse_ce, self.gscale, self.n_mods,
+                           loss_w=self.loss_w[c:c + 1] if getattr(self, "_loss_mode", 0) else None)
             ops.gemm_nt(lg, l.wt, self.dyn, ub, D, V, L.EPI_BF16, m_range=self.ranges[c], lda=V, ldb=V, ldc=D)
             self._wgrad(l.g, lg, self.yn, V, D, ub, ldp=V, ldq=D, m_range=self.ranges[c])
         for m in reversed(mods):
@@ -778,7 +802,7 @@ class Engine:
             ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
                               self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
             first_ctx = False
-            dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"])
+            dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"], groups=self._dec_groups())
             done(pre)
         if cfg.decoder_depth == 0:
             self.dctx[:RN].zero_()

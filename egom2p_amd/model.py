@@ -328,8 +328,8 @@ class EgoM2P(nn.Module):
 
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], num_encoder_tokens: int, num_decoder_tokens: int,
                 loss_type: str = "mod", return_logits: bool = False):
-        if loss_type not in ("mod", "modality"):
-            raise NotImplementedError("only loss_type='mod' is on the accelerated path")
+        if loss_type not in ("mod", "modality", "weighted_mod", "token"):
+            raise ValueError("Invalid loss type")                        # egom2p_model.py:579
         names = [m.name for m in self._mods if m.name in mod_dict]
         if len(names) != len(self._mods):
             raise NotImplementedError("every configured modality must be present in mod_dict")
@@ -346,7 +346,7 @@ class EgoM2P(nn.Module):
         order = [k for k, _ in random.sample(list(md.items()), len(md))]
         if return_logits:
             return self.engine.forward_logits(md, order)
-        loss, mod_loss = self.engine.forward(md, dec_order=order)
+        loss, mod_loss = self.engine.forward(md, dec_order=order, loss_type=loss_type)
         if torch.is_grad_enabled():
             loss = _LossFn.apply(self._anchor, self, loss)
         else:

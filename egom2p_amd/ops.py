@@ -137,15 +137,28 @@ def gemm_kernel_mode(nt256=1, tn256=1):
     check(L.load().ego_gemm_kernel_mode(nt256, tn256), "ego_gemm_kernel_mode")
 
 
+def gemm_small_tiles(max_tiles128):
+    """NT launches of at most this many 128x128 tiles use the 64x64-tile small-grid kernel (0 = never, < 0 = query); returns the
+    previous threshold"""
+    return L.load().ego_gemm_small_tiles(int(max_tiles128))
+
+
 def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
     """Split-K factor for `gemm_tn`, asked from the launcher itself (ego_gemm_tn_plan)."""
     return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))
 
 
 def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None,
-             hd_pad=64):
+             hd_pad=64, seg=None, seg_bad=None):
     """o_lo (optional device pointer, laid out like o): receives the bf16 rounding residual of the output.
-    hd_pad: elements per stored head (64: the throughput kernels; 96 / 128: zero-padded heads of another dimension)"""
+    hd_pad: elements per stored head (64: the throughput kernels; 96 / 128: zero-padded heads of another dimension)
+    seg (int32 [B, n_seg, 2], optional; head_dim 64 only): row groups of a block-diagonal self-attention mask, seg_bad (int32 [B],
+    optional): samples that must take the per-row intervals instead (ego_attn_fwd_d64_seg)"""
+    if hd_pad == 64 and seg is not None:
+        check(L.load().ego_attn_fwd_d64_seg(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
+                                            r_bs, r_rs, _p(seg), seg.shape[-2], _p(seg_bad), B, H, Nq, Nk, scale, _stream()),
+              "ego_attn_fwd_d64_seg")
+        return
     if hd_pad != 64:
         check(L.load().ego_attn_fwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
                                        r_bs, r_rs, B, H, Nq, Nk, hd_pad, scale, _stream()), "ego_attn_fwd_hd")
@@ -155,7 +168,14 @@ def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks
 
 
 def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
-             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None, hd_pad=64):
+             dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None, hd_pad=64,
+             seg=None, seg_bad=None):
+    if hd_pad == 64 and seg is not None:
+        check(L.load().ego_attn_bwd_d64_seg(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
+                                            _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
+                                            _p(ks), _p(ke), r_bs, r_rs, _p(seg), seg.shape[-2], _p(seg_bad), B, H, Nq, Nk, scale,
+                                            _stream()), "ego_attn_bwd_d64_seg")
+        return
     if hd_pad != 64:
         check(L.load().ego_attn_bwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                        _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
@@ -206,8 +226,9 @@ def ce_fwd(logits, ld, V, targets, rng, max_rows, lse, nll):
     check(L.load().ego_ce_fwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(nll), _stream()), "ego_ce_fwd")
 
 
-def ce_bwd(logits, ld, V, targets, rng, max_rows, lse, gscale, n_mods):
-    check(L.load().ego_ce_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(gscale), n_mods, _stream()),
+def ce_bwd(logits, ld, V, targets, rng, max_rows, lse, gscale, n_mods, loss_w=None):
+    """loss_w: 1-element view of this modality's entry of `loss_weights` (None: loss_type 'mod')"""
+    check(L.load().ego_ce_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(gscale), n_mods, _p(loss_w), _stream()),
           "ego_ce_bwd")
 
 
@@ -216,13 +237,23 @@ def ce_fusable(V):
     return V % 8 == 0 and V <= 65536
 
 
-def ce_fwd_bwd(logits, ld, V, targets, rng, max_rows, lse, nll, gscale, n_mods):
-    check(L.load().ego_ce_fwd_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(nll), _p(gscale), n_mods,
+def ce_fwd_bwd(logits, ld, V, targets, rng, max_rows, lse, nll, gscale, n_mods, loss_w=None):
+    check(L.load().ego_ce_fwd_bwd(_p(logits), ld, V, _p(targets), _p(rng), max_rows, _p(lse), _p(nll), _p(gscale), n_mods, _p(loss_w),
                                   _stream()), "ego_ce_fwd_bwd")
 
 
-def loss_finalize(nll, ranges, n_mods, out, err=None):
-    check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _p(err), _stream()), "ego_loss_finalize")
+LOSS_MODES = {"mod": 0, "modality": 0, "weighted_mod": 1, "token": 2}
+
+
+def loss_weights(ranges, vocab, mode, loss_w, mod_scale):
+    """per-modality loss weights of loss_type 'weighted_mod' (mode 1) / 'token' (mode 2) from the device-side row counts"""
+    arr = (C.c_int * len(vocab))(*[int(v) for v in vocab])
+    check(L.load().ego_loss_weights(_p(ranges), arr, len(vocab), mode, _p(loss_w), _p(mod_scale), _stream()), "ego_loss_weights")
+
+
+def loss_finalize(nll, ranges, n_mods, out, err=None, loss_w=None, mod_scale=None):
+    check(L.load().ego_loss_finalize(_p(nll), _p(ranges), n_mods, _p(out), _p(err), _p(loss_w), _p(mod_scale), _stream()),
+          "ego_loss_finalize")
 
 
 def cast_weight(W, Wb=None, Wt=None, rows_dst=None, ld_w=None, ld_t=None):
@@ -272,6 +303,7 @@ def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_
         d.mod_id[i] = mod_ids[i]
     for k in ("ids_keep", "pad", "mod_mask", "slot", "local", "tok", "ks", "ke", "n_valid", "seg", "err"):
         setattr(d, k, out[k].data_ptr())
+    d.seg_bad = out["seg_bad"].data_ptr() if out.get("seg_bad") is not None else None
     check(L.load().ego_compact(C.byref(d), B, _stream()), "ego_compact")
 
 

@@ -86,11 +86,11 @@ class KernelTimer:
             return n
 
         def c_attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, Hh, Nq, Nk, scale, o_lo=None,
-                       hd_pad=64):
+                       hd_pad=64, seg=None, seg_bad=None):
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
             return 4.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((3 if o_lo is not None else 2) * Nq + 2 * Nk)
 
-        def c_attn_bwd(*a, o_lo=None, hd_pad=64):
+        def c_attn_bwd(*a, o_lo=None, hd_pad=64, seg=None, seg_bad=None):
             ks, ke, r_bs, r_rs, B, Hh, Nq, Nk = a[-9], a[-8], a[-7], a[-6], a[-5], a[-4], a[-3], a[-2]
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
             return 10.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((5 if o_lo is not None else 4) * Nq + 4 * Nk)
@@ -117,7 +117,7 @@ class KernelTimer:
             n = int(rng[1].item())
             return 0.0, n * V * 2.0
 
-        def c_ce_bwd(logits, ld, V, targets, rng, max_rows, *a):
+        def c_ce_bwd(logits, ld, V, targets, rng, max_rows, *a, loss_w=None):
             n = int(rng[1].item())
             return 0.0, n * V * 4.0
 
@@ -155,7 +155,7 @@ class KernelTimer:
         def c_loss_perm(seg, canon, slot, tok, B, M, n_mods, *a):
             return 0.0, float(B) * M * 16.0
 
-        def c_loss_finalize(nll, ranges, n_mods, out, err=None):
+        def c_loss_finalize(nll, ranges, n_mods, out, err=None, loss_w=None, mod_scale=None):
             return 0.0, float(ranges[:n_mods, 1].sum().item()) * 4.0
 
         def c_cast_weight(W, Wb=None, Wt=None, **kw):

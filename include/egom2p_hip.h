@@ -6,7 +6,7 @@
  * and a hipStream_t.  They return 0 on success (EGO_ERR_ARG = rejected arguments, EGO_ERR_LAUNCH =
  * launch failed), never allocate caller-visible memory and never synchronise, so every call is capturable
  * in a hipGraph and re-entrant per stream.  The library reads no environment variables; its only process-wide
- * state is the GEMM tile-family selector set by ego_gemm_kernel_mode (a test / tuning hook, default "by shape").
+ * state is the GEMM tile-family selection set by ego_gemm_kernel_mode / ego_gemm_small_tiles (test / tuning hooks, default "by shape").
  *
  * Each declaration cites the reference code it replaces (paths relative to the reference root).
  * All "bf16" pointers are raw 16-bit bfloat16; "row-major [R, C] with ld" means element (r, c) at
@@ -24,8 +24,8 @@ extern "C" {
 /* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
  * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; 3: round 3 gave ego_layernorm_bwd,
  * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; 4: ego_layernorm_fwd / _bwd take the
- * row pitch `ld` beside the normalised width D; loaders must refuse other versions) */
-#define EGO_ABI_VERSION 4
+ * row pitch `ld` beside the normalised width D; 5: ego_compact_desc grew `seg_bad`, ego_ce_bwd / ego_ce_fwd_bwd / ego_loss_finalize take loss weights; loaders must refuse other versions) */
+#define EGO_ABI_VERSION 5
 #define EGO_MAX_MODS 8
 
 /* GEMM epilogues */
@@ -38,6 +38,10 @@ int ego_abi_version(void);
 /* Tile family the GEMM entries may pick (1 = by shape, 0 = 128x128 kernels only, 2 = 256x256 wherever legal); same
  * results up to fp32 summation order.  No reference counterpart: test / tuning hook (tests/test_engine_gpu.py). */
 int ego_gemm_kernel_mode(int nt256, int tn256);
+/* NT launches of at most `max_tiles128` 128x128 output tiles (under-filled grids: the 1707-row linears of the generation
+ * path, egom2p/models/generate.py:747-766) run on the 64x64-tile small-grid kernel; 0 = never, < 0 = query only.  Returns
+ * the previous threshold (default 400).  Same results (same K order); test / tuning hook like ego_gemm_kernel_mode. */
+int ego_gemm_small_tiles(int max_tiles128);
 
 /* ---- front end ------------------------------------------------------------------------------- */
 
@@ -62,6 +66,9 @@ typedef struct {
     int* n_valid;                    /* out int32 [B]                                                     */
     int* seg;                        /* out int32 [B, n_mods, 2] (start, count) of each slot's kept rows  */
     int* err;                        /* in/out int32 [1]: |= 1 if the decoder mask is not an interval     */
+    int* seg_bad;                    /* out int32 [B] (decoder only, or NULL): nonzero if some kept unmasked row's interval
+                                        is not exactly its slot's segment (start, count) - ego_attn_*_d64_seg then takes
+                                        the per-row path for that sample                                                  */
 } ego_compact_desc;
 int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream);
 
@@ -179,6 +186,25 @@ int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_
                      const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                      void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
                      int Nq, int Nk, float scale, hipStream_t stream);
+/* The same two for SELF-attention under a block-diagonal mask given as row groups (the decoder's modality-wise mask,
+ * egom2p_model.py:446-481, as ego_compact writes it): seg int32 [B, n_seg, 2] = (first row, row count) of each group of a
+ * sample, ascending and disjoint; every row of a group attends exactly the group's rows.  The kernels cut every group into
+ * tiles of its own, so each workgroup sees ONE interval (the fast path of the per-sample launches: no per-row mask work, no
+ * tile that straddles two groups).  Rows behind the last group, and every row of a sample with seg_bad[b] != 0 (seg_bad
+ * may be NULL), use their per-row intervals ks / ke (r_rs = 1, r_bs = Nq, required) - results are those of
+ * ego_attn_fwd_d64 / ego_attn_bwd_d64 on the same intervals up to fp32 summation order.  Nq == Nk.  seg = NULL: the plain
+ * entry points. */
+int ego_attn_fwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                         long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks, const int* ke,
+                         long r_bs, long r_rs, const int* seg, int n_seg, const int* seg_bad, int B, int H, int Nq, int Nk,
+                         float scale, hipStream_t stream);
+int ego_attn_bwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                         long v_rs, const void* O, long o_bs, long o_rs, const void* O_lo, const void* dO, long do_bs,
+                         long do_rs, const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs,
+                         long dk_rs, void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs,
+                         const int* seg, int n_seg, const int* seg_bad, int B, int H, int Nq, int Nk, float scale,
+                         hipStream_t stream);
+
 
 /* The same two entries for a head dimension other than 64: every head is stored padded with zero columns to
  * hd_pad = 96 or 128 elements (the registered ego-L, egom2p_model.py:1080-1092, has 15 heads of 68: 68^-0.5 is `scale`),
@@ -241,21 +267,32 @@ int ego_budget_dirichlet(const ego_budget_desc* d, const void* clip_keys, int B,
 /* ---- loss head ------------------------------------------------------------------------------- */
 
 /* F.cross_entropy(reduction='mean') per modality over bf16 logits rows [range[0], range[0]+range[1])
- * (egom2p_model.py:633-644).  bwd overwrites the logits with d loss / d logits (bf16). */
+ * (egom2p_model.py:633-644).  bwd overwrites the logits with d loss / d logits (bf16): (softmax - onehot) * gscale / (n_mods * n)
+ * for loss_type 'mod'; with loss_w (a pointer to THIS modality's entry of ego_loss_weights' loss_w; NULL = 'mod')
+ * (softmax - onehot) * gscale * loss_w[0] / n. */
 int ego_ce_fwd(const void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse,
                float* nll, hipStream_t stream);
 int ego_ce_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, const float* lse,
-               const float* gscale, int n_mods, hipStream_t stream);
+               const float* gscale, int n_mods, const float* loss_w, hipStream_t stream);
 /* ego_ce_fwd and ego_ce_bwd in one pass over the logits (the training step knows the upstream gradient `gscale` when it
  * forms the loss): lse / nll as ego_ce_fwd writes them, the logits overwritten as ego_ce_bwd does, bitwise the two-call
  * result; the rows are read once.  V <= 65536 (a row is held in one workgroup's registers), else EGO_ERR_ARG: the caller
  * then uses the two calls. */
 int ego_ce_fwd_bwd(void* logits, long ld, int V, const int* targets, const int* range, int max_rows, float* lse, float* nll,
-                   const float* gscale, int n_mods, hipStream_t stream);
-/* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality.
+                   const float* gscale, int n_mods, const float* loss_w, hipStream_t stream);
+/* Per-modality loss weights of the reference's other two loss types from the row counts of this batch (ranges[m] = (first
+ * row, rows) on the device): mode 1 = 'weighted_mod' (forward_weighted_mod_loss, egom2p_model.py:583-612: every modality's
+ * mean CE divided by ln(vocab) and multiplied by ln 256, then the mean over modalities), mode 2 = 'token'
+ * (forward_token_loss, :646-681: the modalities' mean CEs weighted by logits.numel() = rows x vocab).  loss_w[m] multiplies
+ * modality m's mean nll in the total, mod_scale[m] the reported per-modality loss.  vocab: HOST array of n_mods sizes. */
+int ego_loss_weights(const int* ranges, const int* vocab, int n_mods, int mode, float* loss_w, float* mod_scale,
+                     hipStream_t stream);
+/* out[0] = mean over modalities of per-modality mean nll (empty modality = 0), out[1+m] = per modality; with loss_w /
+ * mod_scale (ego_loss_weights; NULL = loss_type 'mod'): out[0] = sum_m loss_w[m] * mean_nll[m], out[1+m] = mod_scale[m] * mean_nll[m].
  * err (optional): ego_compact's flag word; if set, every output is NaN (the reference's non-finite-loss exit,
  * run_training_egom2p.py:731-734, then stops the run instead of training on a wrong attention mask) and it is cleared. */
-int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, hipStream_t stream);
+int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* out, int* err, const float* loss_w,
+                      const float* mod_scale, hipStream_t stream);
 
 /* ---- generation (config 4) ------------------------------------------------------------------- */
 

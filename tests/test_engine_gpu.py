@@ -136,9 +136,10 @@ def test_engine_matches_reference(case):
             gap = (lg.max(-1).values - lg.gather(1, ref_am_t[:, None])[:, 0])[mism]
             assert bool((gap <= 3e-2 * lg.abs().max(-1).values[mism]).all()), (m.name, gap.max().item())
         # (random-init heads are nearly flat: measured 2 of 60 flips on the 256-token heads; every flip is a proven near-tie
-        # above).  Floor 0.95: at most 3 of 64 rows may flip - a regression that flips a fifth of the rows inside the near-tie
-        # band does not pass.
-        assert 1.0 - mism.float().mean().item() >= 0.95, (m.name, mism.float().mean().item())
+        # above).  Floor 0.95 (at most 3 of 64 rows may flip - a regression that flips a fifth of the rows inside the near-tie
+        # band does not pass).
+        # (modalities with few rows - 13 in `tiny8` - may have ONE such flip)
+        assert int(mism.sum()) <= max(1, int(0.05 * rows)), (m.name, int(mism.sum()), rows)
 
     # ---- backward + clip + AdamW
     eng.zero_grad()

@@ -145,7 +145,10 @@ def test_roar_cfg_generation_matches_reference(fixture):
         # for the small flat-head logits.  Measured: exactly 20.0 = 2.5 ulps of 8 at |logit| 1136 on the full-depth fixture.
         # The bar is per ROW: 3 ulps of THAT row's largest |mixed logit|, not of the global maximum; the rows
         # that exceed the round-2 bar 0.35 * max(1, 0.02 * row top) are counted and printed for the record.
-        row_top = mixed.abs().max(-1).values.clamp_min(1e-30)
+        # (the rounding sits on the bf16 logits c and u, which can be larger than their mix u + s (c - u): each token's mixed
+        # logit carries s * ulp(c) / 2 + |1 - s| * ulp(u) / 2, two tokens twice that: <= 3 ulps of the row's largest |c|, |u|)
+        row_top = torch.maximum(mixed.abs().max(-1).values, torch.maximum(info["logits_cond"][0].float().abs().max(-1).values,
+                                                                          info["logits_uncond"][0].float().abs().max(-1).values)).clamp_min(1e-30)
         row_bar = torch.clamp(3.0 * torch.exp2(torch.floor(torch.log2(row_top)) - 7), min=0.35)
         old_bar = 0.35 * torch.clamp(0.02 * row_top, min=1.0)
         over_old = int((gap[:, 0] > old_bar).sum())

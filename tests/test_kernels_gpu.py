@@ -65,6 +65,47 @@ def test_gemm_nt_row_range():
     assert (C[:130] == 7).all() and (C[463:] == 7).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(1707, 768, 768), (1706, 2304, 768), (1707, 768, 2048), (1707, 4096, 768), (3414, 1536, 768),
+                                   (65, 72, 64), (5120, 768, 128)])
+def test_gemm_nt_small_grid_kernel_equals_the_128_tile_kernel(M, N, K):
+    """Under-filled NT launches (the 1707-row linears of the generation path) run on 64x64 tiles with a 4-deep LDS-DMA ring
+    (gemm_nt64_kernel): same K order, same MFMA chain per output element -> bit for bit the 128x128 kernel's result, for every
+    epilogue, ragged edges and device-side row ranges included."""
+    A = _bf(torch.randn(M, K, device=DEV))
+    B = _bf(torch.randn(N, K, device=DEV) * 0.1)
+    R = torch.randn(M, N, device=DEV)
+    bias = torch.randn(N, device=DEV)
+    rng = torch.tensor([M // 3, M // 2], device=DEV, dtype=torch.int32)
+    outs = {}
+    old = ops.gemm_small_tiles(-1)
+    try:
+        for mode, thr in (("t128", 0), ("t64", 1 << 30)):
+            ops.gemm_small_tiles(thr)
+            ops.gemm_kernel_mode(0, 1)                       # keep the 256x256 family out of the comparison
+            C = torch.full((M + 2, N), 5.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16)
+            C32 = torch.full((M + 2, N), 3.0, device=DEV)
+            ops.gemm_nt(A, B, C32, M, N, K, L.EPI_F32)
+            o1 = torch.empty(M, N, device=DEV)
+            ops.gemm_nt(A, B, o1, M, N, K, L.EPI_RESID, R=R)
+            o2 = torch.empty(M, N, device=DEV)
+            ops.gemm_nt(A, B, o2, M, N, K, L.EPI_BIAS_RESID, R=R, bias=bias)
+            Cr = torch.full((M, N), 7.0, device=DEV)
+            ops.gemm_nt(A, B, Cr, M, N, K, L.EPI_F32, m_range=rng)
+            outs[mode] = (C, C32, o1, o2, Cr)
+    finally:
+        ops.gemm_small_tiles(old)
+        ops.gemm_kernel_mode(1, 1)
+    for a, b in zip(outs["t128"], outs["t64"]):
+        assert torch.equal(a, b)
+    C, C32, o1, o2, Cr = outs["t64"]
+    ref = A.float() @ B.float().t()
+    assert _rel(C32[:M], ref) < 1e-5 and (C32[M:] == 3).all() and (C[M:] == 5).all()
+    assert _rel(C[:M].float(), ref) < 4e-3
+    lo, n = M // 3, M // 2
+    assert _rel(Cr[lo:lo + n], ref[lo:lo + n]) < 1e-5 and (Cr[:lo] == 7).all() and (Cr[lo + n:] == 7).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(8292, 5120, 192), (8192, 5120, 64), (16384 + 7, 2560, 128), (65536, 768, 768),
                                    (40000, 1152, 1152)])      # ego-L width: the last column tile is half empty
 def test_gemm_nt256_persistent(M, N, K):
@@ -329,6 +370,86 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
     assert _rel(gq, q.grad) < 2e-2, ("dq", _rel(gq, q.grad))
     assert _rel(gk, k.grad) < 2e-2, ("dk", _rel(gk, k.grad))
     assert _rel(gv, v.grad) < 2e-2, ("dv", _rel(gv, v.grad))
+
+
+@pytest.mark.parametrize("B,H,N,groups", [
+    (2, 12, 2048, [[(0, 1009), (1009, 1009), (2018, 15), (2033, 15)], [(0, 1009), (1009, 1009), (2018, 15), (2033, 15)]]),   # the bench's clip
+    (3, 2, 600, [[(0, 130), (130, 0), (130, 300), (430, 7)],       # an empty group, a 163-row tail of padding rows
+                 [(0, 64), (64, 128), (192, 192), (384, 216)],      # tile-aligned groups, no tail
+                 [(0, 1), (1, 1), (2, 1), (3, 590)]]),              # one-row groups, short tail
+    (2, 3, 300, [[(0, 100), (100, 100), (200, 100)], [(0, 100), (100, 100), (200, 100)]]),
+])
+def test_attention_row_groups(B, H, N, groups):
+    """ego_attn_*_d64_seg: block-diagonal self-attention launched by row groups (one interval per workgroup) against fp32 torch
+    on the per-row intervals, and against the per-row launches of the same intervals.  Tail rows (behind the last group) keep
+    arbitrary per-row intervals - pointing into a group, empty (= uniform attention), anything; sample 1 of the last case is
+    flagged seg_bad and carries intervals that are NOT its groups: it must come out as the per-row launch computes it."""
+    D = H * 64
+    n_seg = len(groups[0])
+    qkv = _bf(torch.randn(B, N, 3, D, device=DEV))
+    ks = torch.zeros(B, N, dtype=torch.int32, device=DEV)
+    ke = torch.zeros(B, N, dtype=torch.int32, device=DEV)
+    seg = torch.tensor(groups, dtype=torch.int32, device=DEV)                    # [B, n_seg, 2]
+    bad = torch.zeros(B, dtype=torch.int32, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for b in range(B):
+        end = 0
+        for s0, c in groups[b]:
+            ks[b, s0:s0 + c] = s0
+            ke[b, s0:s0 + c] = s0 + c
+            end = max(end, s0 + c)
+        if end < N:                                               # tail rows: some group's interval, an empty one, or a random one
+            t = N - end
+            pick = torch.randint(0, n_seg + 2, (t,), device=DEV, generator=gen)
+            for i in range(t):
+                j = int(pick[i])
+                if j < n_seg:
+                    ks[b, end + i], ke[b, end + i] = groups[b][j][0], groups[b][j][0] + groups[b][j][1]
+                elif j == n_seg:
+                    ks[b, end + i], ke[b, end + i] = 7, 7
+                else:
+                    ks[b, end + i], ke[b, end + i] = 3, end
+    if B == 2 and N == 300:
+        bad[1] = 1
+        ks[1] = torch.randint(0, 150, (N,), device=DEV, generator=gen).int()
+        ke[1] = ks[1] + torch.randint(0, 150, (N,), device=DEV, generator=gen).int()
+    scale = 0.125
+    q = qkv[:, :, 0].reshape(B, N, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    k = qkv[:, :, 1].reshape(B, N, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    v = qkv[:, :, 2].reshape(B, N, H, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+    ref = _attn_ref(q, k, v, ks.long(), ke.long(), scale)
+    do = _bf(torch.randn(B, N, D, device=DEV))
+    ref.backward(do.view(B, N, H, 64).permute(0, 2, 1, 3).float())
+    p3 = qkv.data_ptr()
+
+    def run(**kw):
+        o = torch.full((B, N, D), 9.0, device=DEV, dtype=torch.bfloat16)
+        lse = torch.empty(B, H, N, device=DEV)
+        delta = torch.empty(B, H, N, device=DEV)
+        dqkv = torch.full((B, N, 3, D), 9.0, device=DEV, dtype=torch.bfloat16)
+        g = dqkv.data_ptr()
+        ops.attn_fwd(p3, N * 3 * D, 3 * D, p3 + 2 * D, N * 3 * D, 3 * D, p3 + 4 * D, N * 3 * D, 3 * D, o.data_ptr(), N * D, D, lse,
+                     ks, ke, N, 1, B, H, N, N, scale, **kw)
+        ops.attn_bwd(p3, N * 3 * D, 3 * D, p3 + 2 * D, N * 3 * D, 3 * D, p3 + 4 * D, N * 3 * D, 3 * D, o.data_ptr(), N * D, D,
+                     do.data_ptr(), N * D, D, lse, delta, g, N * 3 * D, 3 * D, g + 2 * D, N * 3 * D, 3 * D, g + 4 * D, N * 3 * D, 3 * D,
+                     ks, ke, N, 1, B, H, N, N, scale, **kw)
+        torch.cuda.synchronize()
+        return o, lse, dqkv
+
+    o_r, lse_r, d_r = run()
+    o_g, lse_g, d_g = run(seg=seg, seg_bad=bad)
+    hv = lambda t: t.reshape(B, N, H, 64).permute(0, 2, 1, 3).float()
+    assert _rel(hv(o_g), ref) < 1e-2
+    assert _rel(hv(d_g[:, :, 0]), q.grad) < 2e-2 and _rel(hv(d_g[:, :, 1]), k.grad) < 2e-2 and _rel(hv(d_g[:, :, 2]), v.grad) < 2e-2
+    # against the per-row launches: the same arithmetic up to the order of the key tiles (online softmax / fp32 sums)
+    assert _rel(o_g.float(), o_r.float()) < 3e-3 and (lse_g - lse_r).abs().max().item() < 1e-3
+    assert _rel(d_g.float(), d_r.float()) < 5e-3
+    if int(bad.sum()):                       # the flagged sample takes the per-row path itself: bit for bit
+        assert torch.equal(o_g[1], o_r[1]) and torch.equal(d_g[1], d_r[1])
+    # every row written exactly (no 9.0 left), and two launches agree bit for bit
+    assert not (o_g == 9).all(-1).any() and not (d_g == 9).all(-1).any()
+    o_g2, _, d_g2 = run(seg=seg, seg_bad=bad)
+    assert torch.equal(o_g, o_g2) and torch.equal(d_g, d_g2)
 
 
 @pytest.mark.parametrize("hd,hdp", [(68, 96), (68, 128), (66, 128), (96, 96), (120, 128)])
