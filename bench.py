@@ -40,7 +40,7 @@ def flops_per_clip(cfg, budgets, n_enc, n_dec):
     return float(enc + dec + ctx + logits)
 
 
-def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
+def cpu_baseline(cfg, sd, synth, budgets, rank, order, n_enc, n_dec, protocol):
     """The oracle (CPU restatement of the reference's forward, validated against the reference's own outputs) timed on
     the host cores: forward + backward of whole clips of the same workload.  SURVEY.md section 8(d) protocol = one
     warm-up, then the median of 5 runs, for B in {1, 4}, in fp32 and in the autocast-emulating bf16 mode ("full",
@@ -48,7 +48,6 @@ def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
     bf16 mode.  `value` is always the B = 1 fp32 median."""
     import statistics
     from oracle import egom2p_oracle as O
-    sd = {k: v.detach().float().cpu().clone() for k, v in eng.state_dict().items()}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("EGOM2P_CPU_THREADS", "16"))))   # the GPU box's CPU share per GPU is 16
     torch.set_num_threads(cores)
@@ -79,9 +78,129 @@ def cpu_baseline(cfg, eng, synth, budgets, rank, order, n_enc, n_dec, protocol):
                      "clip_positions_per_s": round(B * 10300.0 / med, 1), "loss": loss})
     head = runs[0]
     return {"value": head["clip_positions_per_s"], "unit": "clip-positions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "protocol": protocol + (" (SURVEY 8(d) asks for median of 5 at B in {1, 4}, fp32 and bf16 mode = '--cpu-baseline full', ~20 min: "
+                                    "the default line carries the bounded 'quick' sample so that the run stays within minutes; box-to-box the "
+                                    "value moves 730-930 positions/s)" if protocol == "quick" else ""),
             "sample": f"protocol '{protocol}': B=1 fp32 fwd+bwd of one 10300-position clip (N=M={n_enc}), {head['warmup']} warm-up + "
                       f"median of {head['timed']} ({head['median_s']} s each); all legs {total:.0f} s of CPU work",
             "loss": head["loss"], "runs": runs}
+
+
+def dp_report(reducer, world, sparse=None):
+    """Data-parallel fields of the JSON line (world > 1, or the one-rank rehearsal): which exchange ran and how it overlapped.
+    `exchange_ms` = the buckets' collectives on the comm stream, `exposed_ms` = what the compute stream still waited for at
+    the end of the backward, `overlap_frac` = 1 - exposed / exchange (GradBucketReducer.timing_stats)."""
+    st = reducer.timing_stats() if reducer is not None else None
+    if st is None:
+        return {"parallelism": f"dp{world}"}, {}
+    tag = f"dp{world}:{st['algo']}:{st['backend']}" + (":sparse-tables" if sparse is not None else "")
+    extra = {"exchange_ms": round(st["exchange_ms"], 3), "exposed_ms": round(st["exposed_ms"], 3), "overlap_frac": round(st["overlap_frac"], 4),
+             "exchange_buckets": st["buckets"], "exchange_bytes": st["bytes"],
+             "exchange_gbs": round(st["bytes"] / max(st["exchange_ms"], 1e-9) / 1e6, 3)}
+    return {"parallelism": tag}, extra
+
+
+def generation_flops(cfg, n_cond, n_target, steps, target_vocab):
+    """Algorithmic forward FLOPs of one ROAR + CFG generation of `n_target` tokens conditioned on `n_cond` tokens
+    (generate.py:747-817): per step a conditional pass (encoder over the conditioning + everything
+    decoded so far) and an unconditional one (encoder over the decoded tokens only; step 0: empty context, the
+    cross-attention is skipped), decoder over the step's tokens with unmasked self-attention, logits for them."""
+    D, F, Le, Ld = cfg.dim, cfg.mlp_hidden, cfg.encoder_depth, cfg.decoder_depth
+    per = [n_target // steps + (1 if i < n_target % steps else 0) for i in range(steps)]
+    tot, done = 0.0, 0
+    for M in per:
+        for N in (n_cond + done, done):
+            enc = Le * (8 * N * D * D + 4 * N * N * D + 6 * N * D * F) + 2 * N * D * D
+            cross = (4 * M * D * D + 4 * N * D * D + 4 * M * N * D) if N > 0 else 0
+            dec = Ld * (8 * M * D * D + 4 * M * M * D + cross + 6 * M * D * F)
+            tot += enc + dec + 2 * M * D * target_vocab
+        done += M
+    return float(tot)
+
+
+def extra_config4(device, repeats_b1=5, repeats_b8=3):
+    """BASELINE config 4 (rgb -> depth, `eval_model_rgb2depth.py`: ROAR 3 steps, CFG 2.0, top-p 0.8, the whole schedule one
+    hipGraph) on a fresh full-depth ego-b with random weights: batch-1 latency and batch-8 throughput, in this process."""
+    import time as _t
+    from egom2p_amd.config import MODEL_CFGS
+    from egom2p_amd.eval_generation import TASKS
+    from egom2p_amd.generate import GenerationSampler, build_chained_generation_schedules, init_empty_target_modality, init_full_input_modality
+    from egom2p_amd.model import MODALITY_INFO, create_model
+    from egom2p_amd import synth
+    from egom2p_amd.profiler import PEAK_BF16_TFLOPS
+    t = TASKS["rgb2depth"]
+    mods = ["tok_rgb", "tok_depth", "tok_cam", "tok_gaze"]
+    name = "egom2p_base_12e_12d_swiglu_nobias"
+    torch.set_grad_enabled(False)
+    try:
+        model = create_model(name, encoder_embeddings={m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods},
+                             decoder_embeddings={m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}, modality_info=MODALITY_INFO)
+        model.eval()
+        sampler = GenerationSampler(model, use_graphs=False)
+        schedule = build_chained_generation_schedules(
+            cond_domains=[t["cond"]], target_domains=[t["target"]], tokens_per_target=[t["tokens"]], autoregression_schemes=["roar"],
+            decoding_steps=[t["steps"]], token_decoding_schedules=["linear"], temps=[0.01], temp_schedules=["constant"],
+            cfg_scales=[2.0], cfg_schedules=["constant"], cfg_grow_conditioning=True)
+        f_clip = generation_flops(MODEL_CFGS[name], 5120, t["tokens"], t["steps"], 64000)
+        out = {"workload": "rgb2depth generation: ROAR 3 steps, CFG 2.0, top-p 0.8, 5120 rgb -> 5120 depth tokens, ego-b 12e/12d, one hipGraph per schedule",
+               "algorithmic_tflop_per_clip": round(f_clip / 1e12, 3)}
+        for B, reps in ((1, repeats_b1), (8, repeats_b8)):
+            ids = synth.randint("bench.cfg4", (B, 5, 32, 32), 64000, seed=0)
+            sample = {t["cond"]: {"tensor": ids.to(device)}}
+            sample = init_empty_target_modality(sample, MODALITY_INFO, t["target"], B, t["tokens"], device)
+            sample = init_full_input_modality(sample, MODALITY_INFO, t["cond"], device)
+            sampler.generate_graphed(sample, schedule, seed=0, top_p=0.8, top_k=0.0)          # capture + warm-up
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(reps):
+                sampler.generate_graphed(sample, schedule, seed=0, top_p=0.8, top_k=0.0)
+            torch.cuda.synchronize()
+            dt = (_t.perf_counter() - t0) / reps
+            if B == 1:
+                out["ms_per_clip_b1"] = round(dt * 1e3, 3)
+                out["frac_b1"] = round(f_clip / dt / 1e12 / PEAK_BF16_TFLOPS, 4)
+            else:
+                out["clips_per_s_b8"] = round(B / dt, 3)
+                out["frac_b8"] = round(f_clip * B / dt / 1e12 / PEAK_BF16_TFLOPS, 4)
+        del sampler, model
+        return out
+    finally:
+        torch.set_grad_enabled(True)
+        torch.cuda.empty_cache()
+
+
+def extra_config5(device, clips=64, mb=32, steps=2):
+    """BASELINE config 5 (ego-L ~1.2 B: D = 1152, 18 heads of 64, F = 3072, 24e / 24d; bf16 and bf16 + fp8 forward linears) as
+    training steps of `clips` clips at micro-batch `mb` on fresh engines, in this process."""
+    import time as _t
+    from egom2p_amd import synth
+    from egom2p_amd.config import MODEL_CFGS
+    from egom2p_amd.engine import Engine
+    from egom2p_amd.profiler import PEAK_BF16_TFLOPS
+    from egom2p_amd.trainer import TrainStep
+    cfg = MODEL_CFGS["ego_L_1152"]
+    f_fwd = flops_per_clip(cfg, synth.CANONICAL_BUDGETS, 2048, 2048)
+    out = {"workload": f"ego_L_1152 (1.19 B) training step, {clips} clips, micro-batch {mb}, canonical 10300-position clips",
+           "algorithmic_tflop_per_clip": round(3 * f_fwd / 1e12, 3)}
+    for tag, fp8 in (("bf16", False), ("fp8", True)):
+        eng = Engine(cfg, device, max_batch=mb, n_enc=2048, n_dec=2048, fp8_forward=fp8)
+        eng.init_random(seed=0)
+        mbs = [synth.make_clip_batch_device(cfg, mb, synth.CANONICAL_BUDGETS, seed=100, sample_offset=i * mb, device=device) for i in range(2)]
+        step = TrainStep(eng, lr=1e-4, weight_decay=0.05, clip_grad=1.0)
+        n_mb = clips // mb
+        run = lambda i: step([mbs[(i * n_mb + j) % 2] for j in range(n_mb)])
+        run(0)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for i in range(steps):
+            run(1 + i)
+        torch.cuda.synchronize()
+        dt = (_t.perf_counter() - t0) / steps
+        out[f"clips_per_s_{tag}"] = round(n_mb * mb / dt, 3)
+        out[f"frac_{tag}"] = round(3 * f_fwd * n_mb * mb / dt / 1e12 / PEAK_BF16_TFLOPS, 4)
+        del step, eng, mbs
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(args, argv):
@@ -140,7 +259,19 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
+    ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default=None,
+                    help="gradient exchange per bucket: RCCL all-reduce (ring) or in-place reduce-scatter + all-gather (default: $EGOM2P_DP_ALGO or allreduce)")
+    ap.add_argument("--dp-backend", choices=["torch", "cabi"], default="torch",
+                    help="torch.distributed's RCCL process group, or the C-ABI's own RCCL communicator (ego_dp_*)")
+    ap.add_argument("--sparse-tables", choices=["auto", "on", "off"], default="auto",
+                    help="row-list exchange of the encoder tables' gradients (auto: when it moves fewer bytes than the dense exchange)")
+    ap.add_argument("--preset", choices=["yaml4"], default=None,
+                    help="yaml4: the released yaml's regime - 4 clips per GPU and step, micro-batch 4 (batch_size: 4 of "
+                         "ego-b_mod4_500b_clariden_2048_camcv_depthdenoise.yaml), where the exchange is NOT hidden by the backward")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-4 / config-5 measurements appended after the timed region (N = 1)")
     args = ap.parse_args()
+    if args.preset == "yaml4":
+        args.clips_per_gpu, args.micro_batch = 4, 4
     under_launcher = "WORLD_SIZE" in os.environ and ("TORCHELASTIC_RUN_ID" in os.environ or int(os.environ["WORLD_SIZE"]) > 1)
     if args.gpus > 1 and not under_launcher:
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):     # a stray WORLD_SIZE=1 from a wrapper shell is not a launcher
@@ -198,7 +329,10 @@ def main():
     # clips are synthesised on the device (ego_clip_synth: bit-identical to the host generator, no H2D copy)
     mbs = [synth.make_clip_batch_device(cfg, mb, budgets, seed=100 + rank, sample_offset=i * mb, device=dev) for i in range(pool)]
     step = TrainStep(eng, lr=args.lr, weight_decay=0.05, clip_grad=1.0, world_size=world, seed=rank,
-                     force_reducer=os.environ.get("EGOM2P_FORCE_REDUCER") == "1")
+                     force_reducer=os.environ.get("EGOM2P_FORCE_REDUCER") == "1", clips_per_step=clips,
+                     sparse_tables=args.sparse_tables, dp_algo=args.dp_algo, dp_backend=args.dp_backend)
+    if step.reducer is not None:
+        step.reducer.timing = True
 
     def run_step(i):
         return step([mbs[(i * n_mb + j) % pool] for j in range(n_mb)])
@@ -223,6 +357,7 @@ def main():
         dt = float(t.item())
     final_loss = float(losses[0].item())
 
+    par, dp_extra = dp_report(step.reducer, world, step.sparse)       # the LAST step's exchange (event-timed on the comm stream)
     ms_per_step = dt / args.steps * 1e3
     tokens = world * clips * 10300 * args.steps
     value = tokens / dt
@@ -239,11 +374,12 @@ def main():
         "dtype": "bf16+fp8fwd" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} mod4, synthetic 10300-position clips (1009+1009 rgb, 1009+1009 depth, 15+15 cam, "
                                f"15+15 gaze kept -> N=M=2048), bf16 MFMA GEMM/attention, fp32 residual/LN/CE/AdamW",
-                   "clips_per_gpu_per_step": clips, "micro_batch": mb, "global_batch": clips * world, "parallelism": f"dp{world}"},
+                   "clips_per_gpu_per_step": clips, "micro_batch": mb, "global_batch": clips * world, **par},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices,
         "clips_per_s": value / 10300.0, "final_loss": final_loss,
         "algorithmic_tflops_per_gpu": e2e_tflops, "mfma_frac_end_to_end": e2e_tflops / PEAK_BF16_TFLOPS,
     }
+    out.update(dp_extra)
 
     if rank == 0 and not args.no_kernel_profile:
         # live HIP-event timing of one micro-batch forward+backward, per kernel class
@@ -281,8 +417,25 @@ def main():
                             for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}
         out["kernel_breakdown"] = {k: {"ms": round(v["ms"], 3), "calls": v["calls"], "tflops": round(v["tflops"], 1),
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+    sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, eng, synth, budgets, rank, [m.name for m in cfg.mods], n_enc, n_dec, args.cpu_baseline)
+        sd_cpu = {k: v.detach().float().cpu().clone() for k, v in eng.state_dict().items()}
+    if rank == 0 and world == 1 and not args.no_extras and args.model == "egom2p_base_12e_12d_swiglu_nobias" and not args.fp8:
+        # Driver-witnessed numbers for BASELINE configs 4 and 5 (the headline fields above stay config 2): measured AFTER the
+        # timed region, in this process, on fresh models - the ego-b training engine's 110 GB are released first
+        del step, mbs
+        eng_keep_cfg = eng.cfg
+        del eng
+        torch.cuda.empty_cache()
+        out["extra"] = {}
+        for key, fn in (("config4", extra_config4), ("config5", extra_config5)):
+            try:
+                out["extra"][key] = fn(dev)
+            except Exception as e:                                   # an extra must never cost the headline line
+                out["extra"][key] = {"error": f"{type(e).__name__}: {e}"}
+        eng = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, synth, budgets, rank, [m.name for m in cfg.mods], n_enc, n_dec, args.cpu_baseline)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

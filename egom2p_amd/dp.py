@@ -86,6 +86,13 @@ class GradBucketReducer:
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []     # for tests / introspection
         self.last_launched: List[Tuple[int, int]] = []
+        # optional timing of the exchange (bench.py: `exchange_ms` / `overlap_frac`): event pairs around every bucket's
+        # collectives on the comm stream + one pair around the compute stream's final wait; off by default (no events)
+        self.timing = False
+        self._t_buckets: List = []
+        self._t_wait = None
+        self._t_cpu = 0.0
+        self._last_timing = None
 
     # buckets arrive tail-first and contiguous: [lo, hi) then [lo', lo) ...; merge until >= cap
     def on_bucket(self, name: str, lo: int, hi: int):
@@ -122,16 +129,41 @@ class GradBucketReducer:
 
     def _launch(self, lo: int, hi: int):
         self.launched.append((lo, hi))
+        t0 = t1 = None
+        if self.cuda and self.timing:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._t_buckets.append((t0, t1, hi - lo))
         if self.cuda and self.cabi is not None:
+            if t0 is not None:
+                # the library makes the comm stream wait for the compute stream itself: mirror that wait here so that the
+                # bucket's clock starts when its gradients are final, not when the previous bucket ended
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm_stream.wait_event(ev)
+                t0.record(self.comm_stream)
             self.cabi.allreduce_begin(self.G[lo:hi], self.algo, torch.cuda.current_stream(), self.comm_stream)
+            if t1 is not None:
+                t1.record(self.comm_stream)
         elif self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if t0 is not None:
+                    t0.record(self.comm_stream)
                 self._exchange(lo, hi)
+                if t1 is not None:
+                    t1.record(self.comm_stream)
         else:
+            import time
+            c0 = time.perf_counter()
             self._exchange(lo, hi)
+            if self.timing:
+                for w in self._works:                # gloo: the collectives of this bucket, synchronously
+                    w.wait()
+                self._works.clear()
+                self._t_cpu += time.perf_counter() - c0
+                self._t_buckets.append((None, None, hi - lo))
 
     def finish(self):
         """Flush the tail bucket and make the compute stream wait for every outstanding all-reduce
@@ -143,12 +175,42 @@ class GradBucketReducer:
             self._pending = None
         for w in self._works:
             w.wait()
+        w0 = w1 = None
+        if self.cuda and self.timing:
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record(torch.cuda.current_stream())
         if self.cuda and self.cabi is not None:
             self.cabi.wait(torch.cuda.current_stream(), self.comm_stream)
         elif self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if w0 is not None:
+            w1.record(torch.cuda.current_stream())
+            self._t_wait = (w0, w1)
         self._works.clear()
         self.last_launched, self.launched = self.launched, []
+        if self.timing:
+            self._last_timing = (self._t_buckets, self._t_wait, self._t_cpu)
+            self._t_buckets, self._t_wait, self._t_cpu = [], None, 0.0
+
+    def timing_stats(self):
+        """Timing of the LAST finished exchange (needs `timing = True` before the step; synchronises the device):
+        exchange_ms = time the buckets' collectives took on the comm stream (summed over buckets), exposed_ms = how long the
+        compute stream then still had to wait for them at the end of the backward, overlap_frac = the share of the exchange
+        that ran under the backward (1 - exposed / exchange).  On a CPU group (gloo rehearsal) the collectives are
+        synchronous: exposed = exchange, overlap 0."""
+        if self._last_timing is None:
+            return None
+        buckets, wait, cpu = self._last_timing
+        nbytes = sum(n for _, _, n in buckets) * self.G.element_size()
+        if self.cuda:
+            torch.cuda.synchronize(self.G.device)
+            ex = sum(a.elapsed_time(b) for a, b, _ in buckets)
+            exposed = wait[0].elapsed_time(wait[1]) if wait is not None else 0.0
+        else:
+            ex = exposed = cpu * 1e3
+        frac = 0.0 if ex <= 0 else max(0.0, min(1.0, 1.0 - exposed / ex))
+        return {"exchange_ms": ex, "exposed_ms": exposed, "overlap_frac": frac, "buckets": len(buckets), "bytes": nbytes,
+                "algo": self.algo, "backend": "cabi" if self.cabi is not None else "torch"}
 
 
 class SparseTableExchange:

@@ -19,10 +19,12 @@ from .optim import FusedAdamW
 class TrainStep:
     def __init__(self, engine: Engine, lr: float = 1e-4, weight_decay: float = 0.05, clip_grad: Optional[float] = 1.0,
                  process_group=None, world_size: int = 1, seed: int = 0, force_reducer: bool = False,
-                 clips_per_step: Optional[int] = None, sparse_tables: str = "auto", dp_algo: Optional[str] = None):
+                 clips_per_step: Optional[int] = None, sparse_tables: str = "auto", dp_algo: Optional[str] = None,
+                 dp_backend: str = "torch"):
         """clips_per_step (per rank) bounds the table rows one step can touch (clips x kept encoder tokens); with
         sparse_tables = "auto" the encoder tables' gradients go through the row-list exchange when that moves fewer bytes
-        than the dense all-reduce ("on" / "off" force it)."""
+        than the dense all-reduce ("on" / "off" force it).  dp_algo: "allreduce" | "rs_ag" (GradBucketReducer); dp_backend:
+        "torch" (torch.distributed's RCCL) or "cabi" (the library's own communicator, ego_dp_*; GPU groups only)."""
         self.engine = engine
         self.opt = FusedAdamW(engine, lr=lr, weight_decay=weight_decay, world_size=world_size)
         self.clip = clip_grad
@@ -42,7 +44,13 @@ class TrainStep:
                 if picked:
                     self.sparse = SparseTableExchange([(g, fl) for g, fl, _ in picked], cap, process_group)
                     skip = tuple(f"enc_table.{m.name}" for _, _, m in picked)
-        self.reducer = (GradBucketReducer(engine.G, process_group, force=force_reducer, skip=skip, algo=dp_algo)
+        cabi = None
+        if dp_backend == "cabi" and (world_size > 1 or force_reducer):
+            from .dp import CabiComm
+            cabi = CabiComm(engine.dev, process_group)
+        elif dp_backend not in ("torch", "cabi"):
+            raise ValueError(f"TrainStep: unknown dp_backend {dp_backend!r}")
+        self.reducer = (GradBucketReducer(engine.G, process_group, force=force_reducer, skip=skip, algo=dp_algo, cabi_comm=cabi)
                         if (world_size > 1 or force_reducer) else None)
         self.rng = random.Random(seed)           # decoder modality shuffle (egom2p_model.py:312), per forward
         self.loss_sum = torch.zeros(1 + engine.n_mods, device=engine.dev)

@@ -219,9 +219,12 @@ def decoder_block(y, ctx, sd, p, heads, sa_blocked, xa_blocked, mode, eps):
 
 def forward(sd: Dict[str, torch.Tensor], cfg, mod_dict, n_enc: int, n_dec: int,
             dec_order: Optional[Sequence[str]] = None, mode: str = "fp32",
-            taps: Optional[dict] = None, return_logits: bool = False):
+            taps: Optional[dict] = None, return_logits: bool = False, loss_type: str = "mod"):
     """Returns (loss, {mod: loss}).  `dec_order`: decoder modality order (names); default = dict order.
-    `taps` (optional dict) receives intermediate tensors for parity tests."""
+    `taps` (optional dict) receives intermediate tensors for parity tests.  `loss_type`: 'mod' (forward_mod_loss,
+    egom2p_model.py:614-644), 'weighted_mod' (forward_weighted_mod_loss, :583-612) or 'token' (forward_token_loss, :646-681)."""
+    if loss_type not in ("mod", "modality", "weighted_mod", "token"):
+        raise ValueError("Invalid loss type")
     mods = [m for m in cfg.mods if m.name in mod_dict]
     byname = {m.name: m for m in mods}
     dmods = [byname[n] for n in (dec_order or [m.name for m in mods])]
@@ -289,18 +292,24 @@ def forward(sd: Dict[str, torch.Tensor], cfg, mod_dict, n_enc: int, n_dec: int,
         return {m.name: linear(y, sd[f"decoder_embeddings.{m.name}.to_logits.weight"], mode=mode) for m in mods}
 
     # --- per-modality logits + CE, averaged over *all* modalities (egom2p_model.py:614-644)
-    mod_loss = {}
+    mod_loss, mod_count = {}, {}
     mm = torch.from_numpy(cd["mod_mask"].astype(np.int64))
     tgt = torch.from_numpy(cd["target_ids"])
     for m in mods:        # dict order of decoder_mod_dict == mod_dict order (:712-714)
         sel = mm == m.id
         logits = linear(y[sel], sd[f"decoder_embeddings.{m.name}.to_logits.weight"], mode=mode)
         taps[f"logits.{m.name}"] = logits
+        mod_count[m.name] = logits.numel()                               # rows x vocab (:676)
         if logits.numel() == 0:
             mod_loss[m.name] = logits.sum()
         else:
             mod_loss[m.name] = F.cross_entropy(logits.float(), tgt[sel], reduction="mean")
-    loss = sum(mod_loss.values()) / len(mod_loss)
+            if loss_type == "weighted_mod":                              # :607: rescaled to a 256-entry codebook
+                mod_loss[m.name] = mod_loss[m.name] / math.log(m.vocab_size) * 5.545177444479562
+    if loss_type == "token":                                             # :679
+        loss = sum(mod_loss[k] * mod_count[k] for k in mod_loss) / sum(mod_count.values())
+    else:
+        loss = sum(mod_loss.values()) / len(mod_loss)
     return loss, mod_loss
 
 

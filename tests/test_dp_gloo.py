@@ -176,3 +176,53 @@ def test_sparse_table_exchange_equals_dense_allreduce():
     assert SparseTableExchange.worth_it(64000, 768, 4 * 2048, 8)
     assert not SparseTableExchange.worth_it(64000, 768, 256 * 2048, 8)
     assert not SparseTableExchange.worth_it(256, 768, 4 * 2048, 8)          # cam / gaze tables stay dense
+
+
+def _timing_worker(rank, world, port, ret):
+    """the bench's multi-rank branch without the GPU: a timed bucketed exchange + bench.py's dp_report"""
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_dp", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {}
+    for algo in ("allreduce", "rs_ag"):
+        G = torch.full((300_003,), float(rank + 1))
+        red = GradBucketReducer(G, bucket_cap_mb=0.25, algo=algo)
+        red.timing = True
+        hi = G.numel()
+        for i, n in enumerate([100_001, 50_000, 150_002]):          # three buckets, tail first
+            red.on_bucket(f"b{i}", hi - n, hi)
+            hi -= n
+        red.finish()
+        assert torch.equal(G, torch.full_like(G, 3.0))               # 1 + 2 on every element, every bucket exchanged exactly once
+        par, extra = bench.dp_report(red, world)
+        out[algo] = (par, extra)
+    assert bench.dp_report(None, 1) == ({"parallelism": "dp1"}, {})
+    if rank == 0:
+        ret.put(out)
+    dist.destroy_process_group()
+
+
+def test_bench_dp_report_over_gloo_world2():
+    """`bench.py --gpus N` records WHICH exchange ran and how it overlapped (`config.parallelism` = dp<N>:<algo>:<backend>,
+    `exchange_ms`, `exposed_ms`, `overlap_frac`, bytes and bucket count from event / wall-clock pairs around every bucket's
+    collectives): rehearsed with two gloo ranks on CPU tensors - the same reducer code path the GPU ranks take."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timing_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for algo in ("allreduce", "rs_ag"):
+        par, extra = out[algo]
+        assert par == {"parallelism": f"dp2:{algo}:torch"}
+        assert extra["exchange_bytes"] == 300_003 * 4 and extra["exchange_buckets"] >= 2
+        assert extra["exchange_ms"] > 0 and extra["exposed_ms"] == extra["exchange_ms"] and extra["overlap_frac"] == 0.0   # gloo: synchronous
+        assert extra["exchange_gbs"] > 0

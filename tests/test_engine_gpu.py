@@ -368,3 +368,51 @@ def test_fp8_forward_stays_within_stated_tolerance(case):
     print(case, "fp8 worst grad-norm error", worst, "total", abs(total - float(g["grad_total_norm"])) / float(g["grad_total_norm"]))
     assert worst[1] < 1e-1, worst
     assert abs(total - float(g["grad_total_norm"])) < 3e-2 * float(g["grad_total_norm"])
+
+
+@pytest.mark.parametrize("case", ["tiny_pad", "tiny8", "b2_ragged"])
+@pytest.mark.parametrize("loss_type", ["weighted_mod", "token"])
+def test_loss_types_match_reference(case, loss_type):
+    """`loss_type='weighted_mod'` / `'token'` (egom2p_model.py:583-612, 646-681) on the engine: the device-side loss weights
+    (ego_loss_weights) in the loss AND in the CE backward, against the REAL reference's loss / per-modality losses / gradient
+    norms (tests/golden/loss_types.npz), with the two-call CE and with the one-pass CE of the training step."""
+    import os
+    g, meta = load_golden(case)
+    cfg = MODEL_CFGS[meta["cfg"]]
+    lt = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_types.npz"), allow_pickle=False)
+    pre = f"{case}.{loss_type}"
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    order = [str(x) for x in g["dec_order"]]
+    eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"])
+    eng.load_state_dict(sd)
+    grads = []
+    for fused in (False, True):
+        loss, mod_loss = eng.forward(mdg, dec_order=order, loss_type=loss_type, loss_grad=1.0 if fused else None)
+        eng.zero_grad()
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        ref_loss = float(lt[f"{pre}.loss"])
+        assert abs(loss.item() - ref_loss) < LOSS_RTOL * abs(ref_loss), (loss.item(), ref_loss)
+        for n, r in zip(lt[f"{pre}.mod_names"], lt[f"{pre}.mod_loss"]):
+            assert abs(mod_loss[str(n)].item() - float(r)) < LOSS_RTOL * max(abs(float(r)), 1.0), n
+        worst = ("", 0.0)
+        for n, r in zip(lt[f"{pre}.grad_names"], lt[f"{pre}.grad_sqnorm_all"]):
+            got = eng.grad_of(str(n)).double().pow(2).sum().item() ** 0.5
+            if r < 0:
+                assert got == 0.0, n
+                continue
+            err = abs(got - r ** 0.5) / max(r ** 0.5, 1e-12)
+            if err > worst[1]:
+                worst = (str(n), err)
+        assert worst[1] < GRAD_TOL, worst
+        grads.append(eng.G.clone())
+    assert torch.equal(grads[0], grads[1])                      # the one-pass CE is bitwise the two-call form here too
+
+
+def test_invalid_loss_type_is_the_reference_error():
+    cfg = MODEL_CFGS["ego_tiny_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=1, n_enc=30, n_dec=30)
+    with pytest.raises(ValueError, match="Invalid loss type"):
+        eng.forward({}, loss_type="tokens")

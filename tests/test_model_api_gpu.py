@@ -289,6 +289,78 @@ def test_training_script_resumes_where_it_stopped(tmp_path):
         assert torch.equal(ca["optimizer"][k], cb["optimizer"][k]), (k, (ca["optimizer"][k] - cb["optimizer"][k]).abs().max().item())
 
 
+def test_training_script_frozen_phase_schedules_and_evaluate(tmp_path):
+    """run_training_egom2p.py, the host side of the reference's loop: (a) the frozen-model phase (run_training_egom2p.py:117-138,
+    524-527, 686-693): during --frozen_model_epochs only the embeddings (and what freeze_shared_params leaves trainable)
+    move, at the constant frozen lr; (b) lr AND weight decay set per loader step from the schedule arrays (:707-713), here
+    inverse_sqrt with a cool-down and a weight-decay end value; (c) evaluate (:800-835): a no-grad pass over held-out clips
+    whose averages land in the epoch's stats and in log.txt, leave every parameter and the AdamW state untouched, and repeat
+    bit for bit when run again."""
+    import importlib.util
+    import json
+    import os
+    from egom2p_amd.scheduler import build_schedules
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_training_egom2p_amd2", os.path.join(root, "run_training_egom2p.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    out = str(tmp_path / "run")
+    argv = ["--model", "egom2p_tiny_6e_6d_swiglu_nobias", "--in_domains", "tok_cam-tok_gaze", "--out_domains", "tok_cam-tok_gaze",
+            "--num_input_tokens", "32", "--num_target_tokens", "32", "--batch_size", "4", "--epochs", "3", "--epoch_size", "12",
+            "--clip_grad", "1.0", "--blr", "1e-3", "--min_blr", "1e-5", "--print_freq", "100", "--seed", "5", "--output_dir", out,
+            "--frozen_model_epochs", "1", "--frozen_model_blr", "5e-4", "--scheduler", "inverse_sqrt-20", "--warmup_steps", "2",
+            "--cooldown_steps", "2", "--weight_decay", "0.05", "--weight_decay_end", "0.01", "--eval_steps", "2", "--eval_freq", "1",
+            "--loss_type", "token"]
+    snaps, groups, evals = [], [], []
+    real_train, real_eval = R.train_one_epoch, R.evaluate
+
+    def spy_train(model, loader, optimizer, scaler, args, epoch, *rest):
+        if epoch == 0:
+            snaps.append({k: v.detach().clone() for k, v in model.module.state_dict().items()})
+        r = real_train(model, loader, optimizer, scaler, args, epoch, *rest)
+        snaps.append({k: v.detach().clone() for k, v in model.module.state_dict().items()})
+        groups.append([(g["lr"], g["weight_decay"]) for g in optimizer.param_groups])
+        return r
+
+    def spy_eval(model, loader, device, args, prefix="[Eval] "):
+        before = model.module.engine.P.clone()
+        a = real_eval(model, loader, device, args, prefix)
+        b = real_eval(model, loader, device, args, prefix)           # the same held-out clips again (fresh decoder-order stream)
+        assert torch.equal(before, model.module.engine.P)
+        evals.append((a, b))
+        return a
+
+    env_keys = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    R.train_one_epoch, R.evaluate = spy_train, spy_eval
+    try:
+        args = R.get_args(argv)
+        R.main(args)
+    finally:
+        R.train_one_epoch, R.evaluate = real_train, real_eval
+        os.environ.update(env_keys)
+    shared = lambda k: k.startswith(("encoder.", "decoder.", "encoder_norm", "decoder_norm"))
+    init, e0, e1 = snaps[0], snaps[1], snaps[2]
+    moved = lambda a, b, k: not torch.equal(a[k], b[k])
+    trainable = [k for k in init if not (k.endswith("pos_emb") or (k.endswith(".bias") and "norm" in k))]
+    assert all(not moved(init, e0, k) for k in trainable if shared(k))                        # frozen epoch: shared blocks untouched
+    assert all(moved(init, e0, k) for k in trainable if not shared(k))                        # embeddings, mask token, context projection train
+    assert all(moved(e0, e1, k) for k in trainable)                                           # afterwards everything trains
+    # schedules: 3 loader steps per epoch; the values of an epoch's last step are still in the groups when it returns
+    lr, wd = build_schedules(args, 3)
+    assert len(lr) == 9 and lr[0] == lr[2] == 5e-4 * 4 / 256 and wd[0] == 0.05
+    for ep, grp in enumerate(groups):
+        it = 3 * ep + 2
+        assert grp[0] == (float(lr[it]), float(wd[it])) and grp[1] == (float(lr[it]), 0.0), (ep, grp, lr[it], wd[it])
+    assert wd[-1] == 0.01 and abs(lr[-1] - 1e-5 * 4 / 256) < 1e-12
+    # evaluate: repeatable bit for bit, finite, logged
+    assert len(evals) == 3
+    for a, b in evals:
+        assert a == b and set(a) == {"[Eval] loss", "[Eval] tok_cam_loss", "[Eval] tok_gaze_loss"}
+        assert all(np.isfinite(v) and 3.0 < v < 8.0 for v in a.values())
+    lines = [json.loads(x) for x in open(os.path.join(out, "log.txt"))]
+    assert [x["epoch"] for x in lines] == [0, 1, 2] and all("[Eval] loss" in x for x in lines)
+
+
 def test_training_script_reads_reference_token_shards(tmp_path):
     """`run_training_egom2p.py --data_path`: token shards in the reference's on-disk layout (README_DATA.md: one tar per
     modality and shard, '<key>.npz' members) are read by egom2p_amd.data.TokenShards, masked on the device by

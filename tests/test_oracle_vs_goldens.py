@@ -130,3 +130,29 @@ def test_bf16_mode_close_to_fp32():
         l32, _ = O.forward(sd, cfg, md, meta["n_enc"], meta["n_dec"], dec_order=order, mode="fp32")
         l16, _ = O.forward(sd, cfg, md, meta["n_enc"], meta["n_dec"], dec_order=order, mode="bf16")
     assert abs(l32.item() - l16.item()) < 2e-3 * abs(l32.item())
+
+
+@pytest.mark.parametrize("case", ["tiny_pad", "tiny8", "b2_ragged"])
+@pytest.mark.parametrize("loss_type", ["weighted_mod", "token"])
+def test_loss_types_match_reference(case, loss_type):
+    """`loss_type='weighted_mod'` / `'token'` (egom2p_model.py:583-612, 646-681): loss, per-modality losses and every
+    parameter's gradient norm of the REAL reference (tests/golden/loss_types.npz, oracle/make_goldens_loss_types.py)."""
+    g, meta, cfg, sd, md = _setup(case)
+    lt = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_types.npz"), allow_pickle=False)
+    pre = f"{case}.{loss_type}"
+    torch.set_num_threads(8)
+    leaf = O.make_leaf_state(sd)
+    loss, mod_loss = O.forward(leaf, cfg, md, meta["n_enc"], meta["n_dec"], dec_order=[str(x) for x in g["dec_order"]],
+                               mode="fp32", loss_type=loss_type)
+    loss.backward()
+    assert abs(loss.item() - float(lt[f"{pre}.loss"])) < FP32_TOL * abs(float(lt[f"{pre}.loss"]))
+    for n, r in zip(lt[f"{pre}.mod_names"], lt[f"{pre}.mod_loss"]):
+        assert abs(mod_loss[str(n)].item() - float(r)) < FP32_TOL * max(abs(float(r)), 1.0), n
+    for n, r in zip(lt[f"{pre}.grad_names"], lt[f"{pre}.grad_sqnorm_all"]):
+        t = leaf[str(n)]
+        if r < 0:
+            continue
+        got = t.grad.double().pow(2).sum().item() ** 0.5
+        assert abs(got - r ** 0.5) < 1e-4 * max(r ** 0.5, 1e-12), (n, got, r ** 0.5)
+    # and the default type of the same fixture file is the case's own golden
+    assert float(lt[f"{case}.mod.loss"]) == float(g["loss"])
