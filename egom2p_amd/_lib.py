@@ -50,7 +50,7 @@ class EmbedBwdDesc(C.Structure):
     _fields_ = [
         ("dtable", vp * MAX_MODS), ("dmod", vp * MAX_MODS), ("dbase", vp), ("dx", vp), ("d2", vp),
         ("slot", vp), ("tok", vp), ("rows", i64), ("D", i32), ("n_mods", i32), ("touched", vp * MAX_MODS),
-        ("work", vp), ("work_floats", i64),
+        ("work", vp), ("work_floats", i64), ("vocab", i32 * MAX_MODS),
     ]
 
 
@@ -83,6 +83,9 @@ _SIGS = {
                              i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_d64_seg": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
                              vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, i32, vp, i32, i32, i32, i32, f32, vp],
+    "ego_attn_fwd_split_floats": [i32, i32, i32, i32],
+    "ego_attn_fwd_d64_split": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64,
+                               i32, i32, i32, i32, f32, i32, vp, i64, vp],
     "ego_attn_fwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, i64, i64,
                         i32, i32, i32, i32, i32, f32, vp],
     "ego_attn_bwd_hd": [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp,
@@ -138,7 +141,7 @@ def load():
         for name, args in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = i64 if name.endswith("_work_floats") else i32
+            fn.restype = i64 if name.endswith(("_work_floats", "_split_floats")) else i32
         if lib.ego_abi_version() != ABI_VERSION:
             raise EgoHipError(f"libegom2p_hip.so ABI version {lib.ego_abi_version()} != binding {ABI_VERSION}: rebuild (make -C egom2p_amd/csrc)")
         # kernel experiments: EGO_GEMM_NT256 / EGO_GEMM_TN256 = 0 | 1 | 2 pick the GEMM tile family (the library itself

@@ -39,6 +39,9 @@ struct AttnArgs {
     // sample b, groups ascending and disjoint; every row of a group attends exactly the group's own row range.  Rows behind
     // the last group (and all rows of a sample with seg_bad[b] != 0) take the per-row intervals ks / ke.
     const int* seg; const int* seg_bad; int n_seg;
+    // forward only, optional: the keys of a query tile cut into `kv_splits` runs handled by separate workgroups; each writes its
+    // unnormalised O (fp32 [split][B, H, Nq][64]) and (m, l) (fp32 [split][B, H, Nq][2]) to `split_ws`, attn_combine_kernel joins them
+    int kv_splits; float* split_o; float* split_ml;
     int B, H, Nq, Nk;
     float scale;
     // backward only
@@ -253,12 +256,14 @@ __device__ __forceinline__ void store_rows_bf16_hilo(bf16_t* hi, bf16_t* lo, con
 //     scale 0 (the reference's masked_fill(-finfo.max) + softmax = uniform attention).
 // `scratch`: 64 bytes of LDS.  Returns false (for the whole workgroup) when the tile does not exist.
 // ---------------------------------------------------------------------------------------------
-struct QTile { int h, b, q0, qhi, qrow, ks, ke, kbase, w_ksmax, w_kemin, kt0, kt1; bool flat; };
+struct QTile { int h, b, q0, qhi, qrow, ks, ke, kbase, w_ksmax, w_kemin, kt0, kt1, split; bool flat; };
 __device__ __forceinline__ bool q_tile(const AttnArgs& p, char* scratch, QTile& q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int splits = p.kv_splits > 1 ? p.kv_splits : 1;
     const int tiles = ((p.Nq + 127) >> 7) + (p.seg ? p.n_seg + 1 : 0);
     int pair, tile;
-    pair_tile(blockIdx.x, p.B * p.H, tiles, p.r_rs == 0 || p.seg != nullptr, pair, tile);
+    pair_tile(blockIdx.x, p.B * p.H, tiles * splits, p.r_rs == 0 || p.seg != nullptr, pair, tile);
+    q.split = tile % splits; tile /= splits;
     q.h = pair % p.H; q.b = pair / p.H;
     bool uniform = p.r_rs == 0;
     int g0 = 0;
@@ -293,6 +298,11 @@ __device__ __forceinline__ bool q_tile(const AttnArgs& p, char* scratch, QTile& 
     kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
     q.kbase = (p.seg && uniform) ? kmin : 0;
     q.kt0 = (kmin - q.kbase) >> 6; q.kt1 = (kmax - q.kbase + 63) >> 6;
+    if (splits > 1) {                                   // this workgroup's run of the key tiles (may be empty)
+        const int per = (q.kt1 - q.kt0 + splits - 1) / splits;
+        const int a = q.kt0 + q.split * per;
+        q.kt1 = min(q.kt1, a + per); q.kt0 = min(a, q.kt1);
+    }
     return true;
 }
 
@@ -455,6 +465,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     }
 
     const float lt = xhalf_sum(l);
+    if (p.kv_splits > 1) {
+        // partial result of this run of keys: O^T unnormalised (relative to the run's own reference m), m and l per row
+        if (q0 + ql < qhi) {
+            const long row = ((long)b * p.H + h) * p.Nq + qrow;
+            const long all = (long)p.B * p.H * p.Nq;
+            float* po = p.split_o + ((long)qt.split * all + row) * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(f32x4*)(po + db * 32 + 8 * g + 4 * hh) = f32x4{ot[db][4 * g], ot[db][4 * g + 1], ot[db][4 * g + 2], ot[db][4 * g + 3]};
+            if (hh == 0) { float* pm = p.split_ml + ((long)qt.split * all + row) * 2; pm[0] = m; pm[1] = lt; }
+        }
+        return;
+    }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     if (q0 + ql < qhi) {
         const long oo = (long)b * p.o_bs + (long)qrow * p.o_rs + h * 64;
@@ -462,6 +487,34 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
         else store_rows_bf16(p.O + oo, ot, inv, hh);
         if (hh == 0) p.LSE[((long)b * p.H + h) * p.Nq + qrow] = -(m + __builtin_amdgcn_logf(lt));  // v_log_f32 = log2; stored NEGATED
     }
+}
+
+// Joins the kv_splits partial results of a forward launch: per (b, h, row) M = max m_s, w_s = exp2(m_s - M), O = sum w_s O_s /
+// sum w_s l_s.  A run that saw no key has m = -1e30, l = 0 (weight 0).  16 threads x 4 dims per row, 16 rows per workgroup.
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p) {
+    const long all = (long)p.B * p.H * p.Nq;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= all) return;
+    const int d4 = (threadIdx.x & 15) * 4;
+    float M = NEG_BIG;
+    for (int s = 0; s < p.kv_splits; ++s) M = fmaxf(M, p.split_ml[((long)s * all + row) * 2]);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int s = 0; s < p.kv_splits; ++s) {
+        const float* ml = p.split_ml + ((long)s * all + row) * 2;
+        const float w = ml[1] > 0.f ? __builtin_amdgcn_exp2f(ml[0] - M) : 0.f;
+        L += w * ml[1];
+        const f32x4 v = *(const f32x4*)(p.split_o + ((long)s * all + row) * 64 + d4);
+        o += v * w;
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    const int q = (int)(row % p.Nq);
+    const long bh = row / p.Nq;
+    const int h = (int)(bh % p.H);
+    const long b = bh / p.H;
+    bf16_t* dst = p.O + b * p.o_bs + (long)q * p.o_rs + h * 64 + d4;
+    *(u32x2*)dst = u32x2{pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv)};
+    if (p.LSE && d4 == 0) p.LSE[row] = -(M + __builtin_amdgcn_logf(L));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -981,6 +1034,36 @@ extern "C" int ego_attn_fwd_d64_seg(const void* Q, long q_bs, long q_rs, const v
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || !check_seg(a) || o_rs % 8 || o_bs % 8 || (((uintptr_t)O) & 15) || (((uintptr_t)O_lo) & 15)) return EGO_ERR_ARG;    // 16-byte output rows
     EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128 + (a.seg ? a.n_seg + 1 : 0))), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" long ego_attn_fwd_split_floats(int B, int H, int Nq, int kv_splits) {
+    return kv_splits > 1 ? (long)kv_splits * B * H * Nq * 66 : 0;
+}
+
+extern "C" int ego_attn_fwd_d64_split(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
+                                      const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, float* LSE,
+                                      const int* ks, const int* ke, long r_bs, long r_rs, int B, int H, int Nq, int Nk, float scale,
+                                      int kv_splits, float* ws, long ws_floats, hipStream_t stream) {
+    if (kv_splits <= 1)
+        return ego_attn_fwd_d64_seg(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, nullptr, LSE, ks, ke, r_bs, r_rs, nullptr, 0,
+                                    nullptr, B, H, Nq, Nk, scale, stream);
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+    a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+    a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (B == 0 || Nq == 0) return EGO_OK;
+    if (!check(a) || o_rs % 8 || o_bs % 8 || (((uintptr_t)O) & 15) || kv_splits > 16 || !ws || (((uintptr_t)ws) & 15) ||
+        ws_floats < ego_attn_fwd_split_floats(B, H, Nq, kv_splits)) return EGO_ERR_ARG;
+    a.kv_splits = kv_splits;
+    a.split_o = ws;
+    a.split_ml = ws + (long)kv_splits * B * H * Nq * 64;
+    EGO_LAUNCH(attn_fwd_kernel, dim3(B * H * ((Nq + 127) / 128) * kv_splits), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    const long rows = (long)B * H * Nq;
+    EGO_LAUNCH(attn_combine_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, a);
     LAUNCH_CHECK();
     return EGO_OK;
 }

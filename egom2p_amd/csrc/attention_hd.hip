@@ -458,7 +458,8 @@ extern "C" int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* 
     a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a, hd_pad)) return EGO_ERR_ARG;
+    // 16-byte row fragments in and out, like ego_attn_fwd_d64
+    if (!check(a, hd_pad) || ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O) | ((uintptr_t)O_lo)) & 15)) return EGO_ERR_ARG;
     const dim3 grid(B * H * ((Nq + 127) / 128));
     if (hd_pad == 96) { EGO_LAUNCH(hd_fwd_kernel<96>, grid, dim3(256), 0, stream, a); }
     else { EGO_LAUNCH(hd_fwd_kernel<128>, grid, dim3(256), 0, stream, a); }
@@ -483,7 +484,9 @@ extern "C" int ego_attn_bwd_hd(const void* Q, long q_bs, long q_rs, const void* 
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a, hd_pad) || do_rs % 8 || do_bs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4) return EGO_ERR_ARG;
+    if (!check(a, hd_pad) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 ||
+        ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O) | ((uintptr_t)O_lo) | ((uintptr_t)dO) | ((uintptr_t)dQ) |
+          ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;      // 16-byte row fragments, gradient rows included
     const long rows = (long)B * H * Nq;
     const dim3 gq(B * H * ((Nq + 127) / 128)), gk(B * H * ((Nk + 127) / 128)), gd((unsigned)((rows + 255) / 256));
     if (hd_pad == 96) {

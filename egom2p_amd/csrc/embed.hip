@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void embed_sums_kernel(EmbedBwdArgs a) {
             }
         }
     };
-    const long r0 = (long)blockIdx.x * ES_ROWS + wave * 32;
+    const int waves = blockDim.x >> 6;                 // 4; 1 when four row sets of (n_mods + 1) x D floats do not fit the LDS
+    const long r0 = ((long)blockIdx.x * waves + wave) * 32;
     for (int rr = 0; rr < 32; ++rr) {
         const long row = r0 + rr;
         if (row >= a.rows) break;
@@ -346,8 +347,12 @@ __global__ __launch_bounds__(256) void embed_sums_kernel(EmbedBwdArgs a) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < W; i += 256)
-        a.part[(long)blockIdx.x * W + i] = ((lsum[i] + lsum[W + i]) + lsum[2 * W + i]) + lsum[3 * W + i];
+    if (waves == 4) {
+        for (int i = threadIdx.x; i < W; i += 256)
+            a.part[(long)blockIdx.x * W + i] = ((lsum[i] + lsum[W + i]) + lsum[2 * W + i]) + lsum[3 * W + i];
+    } else {
+        for (int i = threadIdx.x; i < W; i += 64) a.part[(long)blockIdx.x * W + i] = lsum[i];
+    }
 }
 
 constexpr int ET_WGS = 512;        // owners of the table rows (token id mod ET_WGS)
@@ -702,8 +707,16 @@ extern "C" int ego_loss_perm(const int* seg, const int* canon, const int* slot, 
     return EGO_OK;
 }
 
+namespace {
+constexpr size_t ES_LDS_MAX = 160 * 1024;      // gfx950: 160 KiB of LDS per workgroup
+// waves per workgroup of embed_sums_kernel: four (one partial row set each, joined in LDS) while the four sets fit, else one
+// wave per workgroup - four times the partial rows for the ordered column sum, same result up to where the partials are cut
+int es_waves(int D, int n_mods) { return (size_t)4 * (n_mods + 1) * D * sizeof(float) <= ES_LDS_MAX ? 4 : 1; }
+}  // namespace
+
 extern "C" long ego_embed_bwd_work_floats(long rows, int D, int n_mods) {
-    return colsum_work_floats((rows + ES_ROWS - 1) / ES_ROWS, (n_mods + 1) * D);
+    const int rows_per_wg = 32 * es_waves(D, n_mods);
+    return colsum_work_floats((rows + rows_per_wg - 1) / rows_per_wg, (n_mods + 1) * D);
 }
 
 extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
@@ -717,11 +730,13 @@ extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
     for (int m = 0; m < EGO_MAX_MODS; ++m) a.touched[m] = d->touched[m];
     a.part = d->work;
     const int W = (d->n_mods + 1) * d->D;
-    const size_t lds = (size_t)4 * W * sizeof(float);
-    if (lds > 160 * 1024) return EGO_ERR_ARG;
-    const long nwg = (d->rows + ES_ROWS - 1) / ES_ROWS;
-#define ES_GO(C) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)embed_sums_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                      EGO_LAUNCH(embed_sums_kernel<C>, dim3((unsigned)nwg), dim3(256), lds, stream, a); } while (0)
+    const int waves = es_waves(d->D, d->n_mods);
+    const size_t lds = (size_t)waves * W * sizeof(float);
+    if (lds > ES_LDS_MAX) return EGO_ERR_ARG;               // (n_mods + 1) * D > 40960: beyond EGO_MAX_MODS x the largest D accepted above
+    const long nwg = (d->rows + 32 * waves - 1) / (32 * waves);
+#define ES_GO(C) do { if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)embed_sums_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                          return EGO_ERR_LAUNCH;                                                                                                \
+                      EGO_LAUNCH(embed_sums_kernel<C>, dim3((unsigned)nwg), dim3(64 * waves), lds, stream, a); } while (0)
     if (d->D <= 768) ES_GO(3); else if (d->D <= 1024) ES_GO(4); else if (d->D <= 1536) ES_GO(6); else ES_GO(8);
 #undef ES_GO
     LAUNCH_CHECK();
@@ -732,9 +747,12 @@ extern "C" int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream) {
     colsum_launch(d->work, nwg, W, dst, stream);
     LAUNCH_CHECK();
     if (tables) {
-        // table ids index 16-bit key fields: vocabularies up to 65536 (the reference's largest is 64000)
+        // table ids index 16-bit key fields: vocabularies up to 65536 (the reference's largest is 64000); a larger id would
+        // alias another row's key: `vocab` (optional, 0 = not given) lets the caller have that checked here
+        for (int m = 0; m < d->n_mods; ++m) if (d->dtable[m] && d->vocab[m] > 65536) return EGO_ERR_ARG;
         const size_t lds2 = (size_t)(5 * ET_CAP + 8) * sizeof(int) + (size_t)4 * d->D * sizeof(float);
-#define ET_GO(C) do { (void)hipFuncSetAttribute((const void*)embed_tables_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+#define ET_GO(C) do { if (hipFuncSetAttribute((const void*)embed_tables_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) \
+                          return EGO_ERR_LAUNCH;                                                                                        \
                       EGO_LAUNCH(embed_tables_kernel<C>, dim3(ET_WGS), dim3(256), lds2, stream, a); } while (0)
         if (d->D <= 768) ET_GO(3); else if (d->D <= 1024) ET_GO(4); else if (d->D <= 1536) ET_GO(6); else ET_GO(8);
 #undef ET_GO

@@ -153,6 +153,12 @@ class TokenShards:
             self.epoch += 1
         self.epoch = epoch0
 
+    @staticmethod
+    def _registry_vocab(name: str) -> int:
+        from .model import MODALITY_INFO
+        info = MODALITY_INFO.get(name)
+        return int(info["vocab_size"]) if info is not None and "vocab_size" in info else 65536
+
     def _collate(self, buf) -> Dict[str, torch.Tensor]:
         out = {}
         for f in self.folders:
@@ -163,9 +169,13 @@ class TokenShards:
             name = self.names[f]
             lo, hi = int(arr.min()), int(arr.max())
             V = self.vocab.get(name)
-            if lo < 0 or (V is not None and hi >= V):
+            if V is None:
+                # no vocabulary given for this modality: fall back to the registry's (a corrupt -1 in a 16-bit shard reads as
+                # 65535 and would index a 64000-row device table out of bounds), else to the 16-bit key range of the tables
+                V = self._registry_vocab(name)
+            if lo < 0 or hi >= V:
                 # nn.Embedding raises an index error in the reference; here ids index device tables directly
-                raise ValueError(f"TokenShards: modality {name}: token ids in [{lo}, {hi}] outside [0, {V if V is not None else 'inf'})")
+                raise ValueError(f"TokenShards: modality {name}: token ids in [{lo}, {hi}] outside [0, {V})")
             t = torch.from_numpy(arr)
             out[name] = t.pin_memory() if self.pin else t
         return out

@@ -78,6 +78,10 @@ class Engine:
         self.HD = cfg.head_dim
         if self.HD == 64:
             self.HDP = 64
+            if (self.H * 64) % 128:
+                # A = H * 64 is the N / K extent of the qkv / proj GEMMs and the pitch of the [rows, A] buffers: the kernels are
+                # validated for multiples of 128 only (an odd head count, e.g. dim 960 = 15 x 64, would need padded heads)
+                raise L.EgoHipError(f"heads of 64 need an even head count (dim={cfg.dim}, heads={cfg.num_heads}: A = {self.H * 64} is not a multiple of 128)")
         else:
             fits = [h for h in (96, 128) if h >= self.HD and (self.H * h) % 128 == 0]
             if not fits:
@@ -106,6 +110,7 @@ class Engine:
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("EGOM2P_WGRAD_STREAM", "0") == "1" else None
         # decoder self-attention launched by row groups (one interval per workgroup); 0: per-row interval launches (round 3)
         self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
+        self.attn_split = os.environ.get("EGOM2P_ATTN_SPLIT", "1") != "0"       # generation path: split keys on under-filled grids
 
     def _ring_next(self):
         self._ring_i = (self._ring_i + 1) % len(self.ring_b)
@@ -565,6 +570,29 @@ class Engine:
                      B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP,
                      seg=seg, seg_bad=seg_bad)
 
+    # generation path: under-filled attention grids (1707 decoder rows x 12 heads = 168 workgroups on 256 CUs, each walking every
+    # key tile serially: 26 - 47 us per launch) get their keys cut into runs (ego_attn_fwd_d64_split) until ~640 workgroups exist
+    SPLIT_TARGET_WGS = 640
+
+    def _kv_splits(self, B, Nq, Nk):
+        base = B * self.H * ((Nq + 127) // 128)
+        if self.HDP != 64 or base <= 0 or not self.attn_split:
+            return 1
+        s = min(8, self.SPLIT_TARGET_WGS // base, ((Nk + 63) // 64) // 4)       # at least four 64-key tiles per run
+        return max(1, s)
+
+    def _attn_infer(self, w, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, ks, ke, B, Nq, Nk):
+        """`_attn` of the generation passes: one interval per sample, no LSE consumer, split keys when the grid is small"""
+        A = self.A
+        sp = self._kv_splits(B, Nq, Nk)
+        ws = w.get("att_ws")
+        if sp > 1 and ws is not None and ws.numel() >= ops.attn_fwd_split_floats(B, self.H, Nq, sp):
+            ops.attn_fwd_split(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
+                               kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, w["lse"], ks, ke, 1, 0,
+                               B, self.H, Nq, Nk, self.scale, sp, ws)
+        else:
+            self._attn(q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, w["lse"], ks, ke, 1, 0, B, Nq, Nk)
+
     def _dec_groups(self):
         """Row groups of the decoder's block-diagonal self-attention mask for the attention kernels (head dim 64): the
         compaction's (start, count) per modality slot + its per-sample "not the contract's mask" flags.  With them every
@@ -892,6 +920,10 @@ class Engine:
             zero_b=torch.zeros(B, device=dev, dtype=I32), full_m=torch.zeros(B, device=dev, dtype=I32),
             dslot=torch.zeros(B * Mmax, device=dev, dtype=I32), dtok=torch.zeros(B * Mmax, device=dev, dtype=I32),
         )
+        # scratch of the split-key attention launches: only query-row counts whose grid is under-filled ever use it
+        rows_split = min(max(Nmax, Mmax), 128 * max(1, self.SPLIT_TARGET_WGS // (2 * B * H)))
+        w["att_ws"] = (e(8 * B * H * rows_split * 66, dt=F32) if (self.HDP == 64 and self.attn_split and B * H * ((rows_split + 127) // 128) * 2 <= self.SPLIT_TARGET_WGS)
+                       else None)
         if not fresh:
             self._iw, self._infer_key = w, key
         return w
@@ -928,7 +960,7 @@ class Engine:
                 pre = f"encoder.{i}"
                 self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
-                self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, N, N)
+                self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], side["n_valid"], B, N, N)
                 self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
                 self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
                 self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
@@ -946,14 +978,14 @@ class Engine:
             pre = f"decoder.{i}"
             self._ln(y[:RM], f"{pre}.norm1.weight", w["ln"], w["st"])
             self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RM)
-            self._attn(w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["lse"], w["zero_b"], w["full_m"], 1, 0, B, M, M)
+            self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], w["full_m"], B, M, M)
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RM, L.EPI_RESID, R=y)
             if N > 0:
                 self._ln(yn[:RM], f"{pre}.query_norm.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RM)
                 self._ln(w["ctx"][:RN], f"{pre}.context_norm.weight", w["cn"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
-                self._attn(w["q"], 0, A, w["kv"], 0, A, 2 * A, w["ao"], w["lse"], w["zero_b"], side["n_valid"], 1, 0, B, M, N)
+                self._attn_infer(w, w["q"], 0, A, w["kv"], 0, A, 2 * A, w["ao"], w["zero_b"], side["n_valid"], B, M, N)
                 self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RM, L.EPI_RESID, R=yn)
             else:
                 # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the

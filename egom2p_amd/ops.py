@@ -167,6 +167,18 @@ def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks
                                     r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_fwd_d64")
 
 
+def attn_fwd_split(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, kv_splits, ws):
+    """forward attention (head dim 64) with the keys of every query tile cut into kv_splits runs (under-filled grids); ws: fp32
+    scratch of at least attn_fwd_split_floats(B, H, Nq, kv_splits) floats"""
+    check(L.load().ego_attn_fwd_d64_split(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, _p(lse), _p(ks), _p(ke), r_bs, r_rs,
+                                          B, H, Nq, Nk, scale, kv_splits, _p(ws), 0 if ws is None else ws.numel(), _stream()),
+          "ego_attn_fwd_d64_split")
+
+
+def attn_fwd_split_floats(B, H, Nq, kv_splits):
+    return L.load().ego_attn_fwd_split_floats(B, H, Nq, kv_splits)
+
+
 def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
              dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None, hd_pad=64,
              seg=None, seg_bad=None):
@@ -324,6 +336,7 @@ def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D, touched=None):
     d = L.EmbedBwdDesc()
     for i in range(len(dmods)):
         d.dtable[i] = None if dtables is None or dtables[i] is None else dtables[i].data_ptr()
+        d.vocab[i] = 0 if dtables is None or dtables[i] is None else int(dtables[i].shape[0])
         d.dmod[i] = dmods[i].data_ptr()
         d.touched[i] = None if touched is None or touched[i] is None else touched[i].data_ptr()
     d.dbase = _p(dbase)

@@ -24,7 +24,7 @@ extern "C" {
 /* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
  * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; 3: round 3 gave ego_layernorm_bwd,
  * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; 4: ego_layernorm_fwd / _bwd take the
- * row pitch `ld` beside the normalised width D; 5: ego_compact_desc grew `seg_bad`, ego_ce_bwd / ego_ce_fwd_bwd / ego_loss_finalize take loss weights; loaders must refuse other versions) */
+ * row pitch `ld` beside the normalised width D; 5: ego_compact_desc grew `seg_bad`, ego_embed_bwd_desc `vocab`, ego_ce_bwd / ego_ce_fwd_bwd / ego_loss_finalize take loss weights; loaders must refuse other versions) */
 #define EGO_ABI_VERSION 5
 #define EGO_MAX_MODS 8
 
@@ -97,6 +97,7 @@ typedef struct {
     long rows; int D, n_mods;
     unsigned char* touched[EGO_MAX_MODS];   /* optional uint8 [V] per table: set to 1 for every row that got a gradient */
     float* work; long work_floats;          /* scratch, at least ego_embed_bwd_work_floats(rows, D, n_mods) floats */
+    int vocab[EGO_MAX_MODS];                /* rows of dtable[m] (0 = not given): > 65536 is refused (16-bit table keys) */
 } ego_embed_bwd_desc;
 /* No float atomics: column sums through per-workgroup partial rows + an ordered reduction, the table scatter as a gather by
  * the table row's owner in ascending row order - results are bitwise reproducible.  Vocabularies up to 65536. */
@@ -186,6 +187,17 @@ int ego_attn_bwd_d64(const void* Q, long q_bs, long q_rs, const void* K, long k_
                      const float* LSE, float* DELTA, void* dQ, long dq_bs, long dq_rs, void* dK, long dk_bs, long dk_rs,
                      void* dV, long dv_bs, long dv_rs, const int* ks, const int* ke, long r_bs, long r_rs, int B, int H,
                      int Nq, int Nk, float scale, hipStream_t stream);
+/* ego_attn_fwd_d64 for UNDER-FILLED grids (the generation path's 1707 decoder rows x 12 heads = 168 workgroups on 256 CUs,
+ * egom2p/models/generate.py:747-766): the keys of every query tile are cut into kv_splits runs handled by separate workgroups
+ * (flash-decoding), whose unnormalised outputs and (max, sum) pairs go through `ws` (at least
+ * ego_attn_fwd_split_floats(B, H, Nq, kv_splits) floats, 16-byte aligned) and are joined by a second kernel.  Same result as
+ * ego_attn_fwd_d64 up to the order of the fp32 sums; LSE may be NULL; no O_lo; kv_splits <= 1: the plain launch. */
+long ego_attn_fwd_split_floats(int B, int H, int Nq, int kv_splits);
+int ego_attn_fwd_d64_split(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
+                           long v_rs, void* O, long o_bs, long o_rs, float* LSE, const int* ks, const int* ke, long r_bs,
+                           long r_rs, int B, int H, int Nq, int Nk, float scale, int kv_splits, float* ws, long ws_floats,
+                           hipStream_t stream);
+
 /* The same two for SELF-attention under a block-diagonal mask given as row groups (the decoder's modality-wise mask,
  * egom2p_model.py:446-481, as ego_compact writes it): seg int32 [B, n_seg, 2] = (first row, row count) of each group of a
  * sample, ascending and disjoint; every row of a group attends exactly the group's rows.  The kernels cut every group into

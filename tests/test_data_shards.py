@@ -129,3 +129,9 @@ def test_out_of_range_and_16_bit_token_ids(tmp_path):
     np.savez(os.path.join(root, "cam", "k1.npz"), np.full(30, -3, np.int32))
     with pytest.raises(ValueError, match="tok_cam"):
         next(iter(TokenShards(root, 2, modalities=["rgb", "cam"], pin_memory=False)))
+    # without a `vocab` argument the registry's vocabulary applies: a corrupt -1 in a 16-bit rgb shard reads as 65535 and must not
+    # reach the 64000-row device table
+    np.savez(os.path.join(root, "cam", "k1.npz"), np.arange(30, dtype=np.int16))
+    np.savez(os.path.join(root, "rgb", "k1.npz"), np.full((5, 32, 32), -1, np.int16))
+    with pytest.raises(ValueError, match="tok_rgb"):
+        next(iter(TokenShards(root, 2, modalities=["rgb", "cam"], pin_memory=False)))

@@ -452,6 +452,41 @@ def test_attention_row_groups(B, H, N, groups):
     assert torch.equal(o_g, o_g2) and torch.equal(d_g, d_g2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,splits", [(1, 12, 1707, 1707, 3), (1, 12, 1706, 3414, 4), (2, 3, 200, 333, 2), (1, 2, 130, 8534, 8),
+                                               (1, 2, 64, 100, 5)])
+def test_attention_fwd_split_keys(B, H, Nq, Nk, splits):
+    """ego_attn_fwd_d64_split (under-filled grids of the generation path): the keys of every query tile handled by `splits`
+    workgroups + a combine kernel - against fp32 torch and against the unsplit launch; per-sample key counts (the encoder's
+    padding), runs that see no key at all (more runs than key tiles), LSE as the unsplit kernel writes it."""
+    D = H * 64
+    qb = _bf(torch.randn(B, Nq, D, device=DEV))
+    kvb = _bf(torch.randn(B, Nk, 2, D, device=DEV))
+    ksb = torch.zeros(B, dtype=torch.int32, device=DEV)
+    keb = torch.tensor([Nk, max(1, Nk // 3)][:B], dtype=torch.int32, device=DEV)
+    scale = 0.125
+    q = qb.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
+    k = kvb[:, :, 0].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    v = kvb[:, :, 1].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
+    ref = _attn_ref(q, k, v, ksb.long()[:, None].expand(B, Nq), keb.long()[:, None].expand(B, Nq), scale)
+    kp, vp = kvb.data_ptr(), kvb.data_ptr() + D * 2
+    o0 = torch.empty(B, Nq, D, device=DEV, dtype=torch.bfloat16)
+    lse0 = torch.empty(B, H, Nq, device=DEV)
+    ops.attn_fwd(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o0.data_ptr(), Nq * D, D, lse0, ksb, keb, 1, 0,
+                 B, H, Nq, Nk, scale)
+    ws = torch.empty(ops.attn_fwd_split_floats(B, H, Nq, splits), device=DEV)
+    o1 = torch.full((B, Nq, D), 9.0, device=DEV, dtype=torch.bfloat16)
+    lse1 = torch.empty(B, H, Nq, device=DEV)
+    ops.attn_fwd_split(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o1.data_ptr(), Nq * D, D, lse1, ksb, keb, 1, 0,
+                       B, H, Nq, Nk, scale, splits, ws)
+    got = o1.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
+    assert _rel(got, ref) < 1e-2
+    # (both outputs are bf16 roundings of fp32 values that agree to ~1e-6: up to one bf16 ulp apart where a rounding boundary falls between them)
+    assert _rel(o1.float(), o0.float()) < 4e-3 and (lse1 - lse0).abs().max().item() < 1e-3
+    with pytest.raises(L.EgoHipError):                       # scratch too small
+        ops.attn_fwd_split(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o1.data_ptr(), Nq * D, D, lse1, ksb, keb,
+                           1, 0, B, H, Nq, Nk, scale, splits, ws[:-64])
+
+
 @pytest.mark.parametrize("hd,hdp", [(68, 96), (68, 128), (66, 128), (96, 96), (120, 128)])
 @pytest.mark.parametrize("B,H,Nq,Nk,kind", [(2, 3, 200, 333, "ragged"), (1, 5, 1100, 1100, "blocks"), (2, 2, 30, 30, "pad"),
                                              (1, 2, 256, 512, "full"), (3, 2, 100, 160, "sample")])
