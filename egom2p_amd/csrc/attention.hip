@@ -1099,9 +1099,18 @@ extern "C" int ego_attn_bwd_d64_seg(const void* Q, long q_bs, long q_rs, const v
         o_rs % 4 || o_bs % 4 || ((((uintptr_t)dQ) | ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;              // 16-byte gradient rows
     if (Nq > DKV_MAX_QTILES * 64) return EGO_ERR_ARG;          // per-q-tile interval summaries live in LDS
     const int extra = a.seg ? a.n_seg + 1 : 0;
-    EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128 + extra)), dim3(256), 0, stream, a);
+    // timing-only probe builds (tools/abl_attn.sh; never the product): ATT_ONLY 1 = dQ kernel only, 2 = dK / dV kernel only;
+    // DKV_PAD_LDS = extra dynamic LDS bytes for the dK / dV launch (> 2.2 KB: only ONE workgroup fits a CU - the co-residence
+    // experiment of DESIGN section 4e)
+#ifndef ATT_ONLY
+#define ATT_ONLY 0
+#endif
+#ifndef DKV_PAD_LDS
+#define DKV_PAD_LDS 0
+#endif
+    if (ATT_ONLY != 2) { EGO_LAUNCH(attn_bwd_dq_kernel, dim3(B * H * ((Nq + 127) / 128 + extra)), dim3(256), 0, stream, a); }
     LAUNCH_CHECK();
-    EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128 + extra)), dim3(256), 0, stream, a);
+    if (ATT_ONLY != 1) { EGO_LAUNCH(attn_bwd_dkv_kernel, dim3(B * H * ((Nk + 127) / 128 + extra)), dim3(256), DKV_PAD_LDS, stream, a); }
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -497,10 +497,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     };
     // fragment byte offsets inside an operand tile: row = base16 + (lane & 15) (base16 multiple of 16, so
     // row & 7 == lane & 7), chunk = ks * 4 + (lane >> 4), slot = chunk ^ (lane & 7)
+    // bf16: the lane's 16-byte chunk of k-step ks.  fp8: the SAME two chunks - lane group g = lane >> 4 feeds the MFMA with
+    // k-bytes [16 g, 16 g + 16) and [64 + 16 g, 64 + 16 g + 16) of its row instead of the contiguous [32 g, 32 g + 32).  Both
+    // operands use the same map, so the contraction still covers every k exactly once (the block scales are all 1.0), and the
+    // two reads keep the bank pattern the swizzle was built for.  Round 3 read chunks 2 g + ks: lanes 20-27 of the first
+    // ds_read_b128 group then hit exactly the banks of lanes 0-3 / 12-15 - a 2-way conflict on EVERY fragment read, which is
+    // what made an e4m3 K-tile take 1.7 x a bf16 K-tile (-DFP8_FRAG_OLD=1 rebuilds that map for the A/B).
+#ifndef FP8_FRAG_OLD
+#define FP8_FRAG_OLD 0
+#endif
     int foff[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)      // fp8: the two 16-byte halves of the lane's 32 k-bytes; bf16: the lane's chunk of k-step ks
-        foff[ks] = (lane & 15) * 128 + (((FP8 ? 2 * (lane >> 4) + ks : ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks)
+        foff[ks] = (lane & 15) * 128 + ((((FP8 && FP8_FRAG_OLD) ? 2 * (lane >> 4) + ks : ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
     const int a_base = grp * 128 * 128, b_base = wc * 64 * 128;
 
     int id = blockIdx.x, row0, col0;

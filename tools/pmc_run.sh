@@ -12,12 +12,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MB=${MB:-64}
 export EGOM2P_PMC_MICRO_BATCH=$MB
-ARGS="--clips-per-gpu $MB --micro-batch $MB --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile"
+ARGS="--clips-per-gpu $MB --micro-batch $MB --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-extras"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1
 echo "[pmc_run] FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1
 echo "[pmc_run] WRITE_SIZE pass done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --clips-per-gpu $MB --micro-batch $MB --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --clips-per-gpu $MB --micro-batch $MB --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-extras > $OUT/trace.log 2>&1
 echo "[pmc_run] kernel-trace pass done"
 F=$(find $OUT/fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/write -name '*counter_collection.csv' | head -1)

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MB=${MB:-64}
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
-    --output-format csv -d $OUT/sq -- python3 $REPO/bench.py --clips-per-gpu $MB --micro-batch $MB --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile > $OUT/sq.log 2>&1
+    --output-format csv -d $OUT/sq -- python3 $REPO/bench.py --clips-per-gpu $MB --micro-batch $MB --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-extras > $OUT/sq.log 2>&1
 F=$(find $OUT/sq -name '*counter_collection.csv' | head -1)
 cd $REPO
 python3 tools/pmc_sq_summary.py "$F" gpurun_out/${TAG}_sq.json
