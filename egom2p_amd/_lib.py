@@ -69,6 +69,9 @@ _SIGS = {
     "ego_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, vp, i64, vp, vp],
     "ego_layernorm_bwd_work_floats": [i32, i32],
     "ego_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
+    "ego_layernorm_fwd_multi": [vp, i32, vp, vp, vp, vp, i32, i32, i64, f32, vp],
+    "ego_layernorm_bwd_multi_work_floats": [i32, i32, i32],
+    "ego_layernorm_bwd_multi": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
     "ego_gemm_nt_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "ego_gemm_tn_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "ego_quant_fp8_rows": [vp, i64, i64, i32, vp, i64, vp, vp],

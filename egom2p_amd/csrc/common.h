@@ -150,6 +150,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #ifndef EGO_MAX_MODS
 #define EGO_MAX_MODS 8
 #endif
-struct ColsumDst { float* p[EGO_MAX_MODS + 1]; int seg; };
+constexpr int COLSUM_MAX_DST = 32;      // gradient vectors behind one slab of partial rows (embedding: modalities + 1; fused LayerNorm: layers)
+struct ColsumDst { float* p[COLSUM_MAX_DST]; int seg; };
 int colsum_launch(float* parts, long n, int W, const ColsumDst& dst, hipStream_t stream);
 long colsum_work_floats(long n, int W);

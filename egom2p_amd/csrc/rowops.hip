@@ -9,6 +9,18 @@
 
 namespace {
 
+// term + prev with the product rounded FIRST (no fma contraction: hipcc contracts a * b + c by default, and the fused
+// multi-layer backward must sum its layers exactly like the chained single-layer launches do through memory)
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float t = a * b;
+    return t + c;
+}
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 constexpr int LN_MAXC_MAX = 8;   // float4 chunks per lane -> D <= 2048 (kernels are instantiated for 3, 4, 6, 8)
 
 // ---------------------------------------------------------------------------------------------
@@ -20,6 +32,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ rstd_out, const int* __restrict__ out_row,
                                                      int rows, int D, int ld, float eps, unsigned char* __restrict__ q8, long ldq,
                                                      float* __restrict__ qscale) {
+    // (no fma contraction anywhere in the LayerNorm kernels: the single-layer and the multi-layer kernels must agree bit for bit
+    // whatever hipcc packs or fuses in one instantiation and not in another)
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -97,6 +112,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ rstd_in, const float* __restrict__ w,
                                                      const float* dx_in, float* dx_out, bf16_t* dx_bf16,
                                                      float* __restrict__ dw_part, int rows, int D, int ld) {
+    // (no fma contraction anywhere in the LayerNorm kernels: the single-layer and the multi-layer kernels must agree bit for bit
+    // whatever hipcc packs or fuses in one instantiation and not in another)
+#pragma clang fp contract(off)
     __shared__ float red[4][LN_MAXC * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = (D + 3) >> 2, ncl = ld >> 2;      // D = normalised width, ld = row pitch (columns [D, ld): zero gradient)
@@ -142,8 +160,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (c < nc) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (!TAIL || c * 4 + e < D) ? rstd * (g[i][e] - c1 - xh[i][e] * c2) : 0.f;
-                if (dx_in) o += *(const f32x4*)(dx_in + (long)row * ld + c * 4);
+                for (int e = 0; e < 4; ++e) o[e] = (!TAIL || c * 4 + e < D) ? mul_rounded(rstd, g[i][e] - c1 - xh[i][e] * c2) : 0.f;
+                if (dx_in) {      // (term rounded, then added - no fma contraction: ln_bwd_multi_kernel sums its layers the same way, bit for bit)
+                    const f32x4 p_ = *(const f32x4*)(dx_in + (long)row * ld + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = mul_then_add(o[e], 1.0f, p_[e]);
+                }
                 *(f32x4*)(dx_out + (long)row * ld + c * 4) = o;
                 if (dx_bf16) {
                     u32x2 b = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
@@ -166,6 +188,202 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     // colsum_kernel, so the weight gradient is bitwise reproducible - and the 768 same-address atomics per workgroup are gone)
     for (int col = threadIdx.x; col < D; col += 256)
         dw_part[(long)blockIdx.x * D + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+}
+
+// ---------------------------------------------------------------------------------------------
+// One input, L LayerNorms (round 4).  The decoder's `context_norm` of every layer normalises the SAME tensor - the context
+// (egom2p_utils.py:387-391: context_norm(context) per DecoderBlock, egom2p_model.py:520-521) - with its own weight: L = 12
+// launches that each re-read 4 B / element forward, and 12 backward launches that each re-read x and read-modify-write the
+// fp32 context gradient (14 B / element each).  Forward: x and its statistics once, L outputs.  Backward: x once, the L
+// upstream gradients once each, ONE write of dx = sum_l rstd (g_l - mean(g_l) - xhat mean(g_l xhat)) - summed in the order
+// l = L-1 .. 0 with the very expressions of ln_bwd_kernel, so dx is bit for bit what the L chained launches produce - and L
+// weight-gradient partial rows per workgroup (ordered column sums as everywhere).
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MULTI_MAX = COLSUM_MAX_DST;
+struct LnMultiFwd { const float* x; const float* w[LN_MULTI_MAX]; bf16_t* y[LN_MULTI_MAX]; float* mean; float* rstd; int L, rows, D, ld; float eps; };
+
+template <int LN_MAXC, bool TAIL>
+__global__ __launch_bounds__(256) void ln_fwd_multi_kernel(LnMultiFwd a) {
+    // (no fma contraction anywhere in the LayerNorm kernels: the single-layer and the multi-layer kernels must agree bit for bit
+    // whatever hipcc packs or fuses in one instantiation and not in another)
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int D = a.D, nc = (D + 3) >> 2, ncl = a.ld >> 2;
+    const float* xr = a.x + (long)row * a.ld;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) { v[i] = *(const f32x4*)(xr + c * 4); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += (!TAIL || c * 4 + e < D) ? d * d : 0.f; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + a.eps);
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    for (int l = 0; l < a.L; ++l) {
+        const float* w = a.w[l];
+        bf16_t* yr = a.y[l] + (long)row * a.ld;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                const f32x4 ww = *(const f32x4*)(w + c * 4);
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (!TAIL || c * 4 + e < D) ? round_bf16((v[i][e] - mean) * rstd * ww[e]) : 0.f;
+                *(u32x2*)(yr + c * 4) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            } else if (c < ncl) {
+                *(u32x2*)(yr + c * 4) = u32x2{0u, 0u};
+            }
+        }
+    }
+}
+
+// rows per wave of the fused backward (their xhat and dx stay in registers across the layers): two, so that three waves fit a
+// SIMD WITH the next layer's gradients and weights already in flight (a 4-row version at two waves per SIMD and no prefetch
+// across layers ran at 1.7 TB/s: 8 waves per CU, every layer a fresh load -> reduce -> barrier chain)
+constexpr int lnm_rw(int) { return 2; }
+struct LnMultiBwd { const bf16_t* dy[LN_MULTI_MAX]; const float* w[LN_MULTI_MAX]; const float* x; const float* mean; const float* rstd;
+                    const float* dx_in; float* dx_out; bf16_t* dx_bf16; float* dw_part; int L, rows, D, ld; };
+
+template <int LN_MAXC, bool TAIL>
+__global__ __launch_bounds__(256, (LN_MAXC <= 3 ? 3 : 2)) void ln_bwd_multi_kernel(LnMultiBwd a) {
+    // (no fma contraction anywhere in the LayerNorm kernels: the single-layer and the multi-layer kernels must agree bit for bit
+    // whatever hipcc packs or fuses in one instantiation and not in another)
+#pragma clang fp contract(off)
+    constexpr int LNM_RW = lnm_rw(LN_MAXC), LNM_ROWS = 4 * LNM_RW;
+    __shared__ float red[4][LN_MAXC * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row offsets / statistics stay scalar)
+    const int D = a.D, ld = a.ld, nc = (D + 3) >> 2, ncl = ld >> 2;
+    const int row0 = blockIdx.x * LNM_ROWS + wave * LNM_RW;
+    // rows past the end are computed on the last row's data with rstd = 0 and d = 0 (no contribution, never stored): the
+    // loops below are straight-line code
+    f32x4 xh[LNM_RW][LN_MAXC], acc[LNM_RW][LN_MAXC];
+    float rs[LNM_RW];
+    long roff[LNM_RW];
+#pragma unroll
+    for (int r = 0; r < LNM_RW; ++r) {
+        const int row = min(row0 + r, a.rows - 1);
+        const bool live = row0 + r < a.rows;
+        const float mean = a.mean[row];
+        rs[r] = live ? a.rstd[row] : 0.f;
+        roff[r] = (long)row * ld;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[r][i] = acc[r][i];
+            if (c < nc) {
+                const f32x4 xv = *(const f32x4*)(a.x + roff[r] + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xh[r][i][e] = (xv[e] - mean) * rs[r];
+            }
+        }
+    }
+    // gradients / weights of a layer are fetched while the previous one is computed
+    u32x2 raws[LNM_RW][LN_MAXC], raws_n[LNM_RW][LN_MAXC];
+    f32x4 ww[LN_MAXC], ww_n[LN_MAXC];
+    auto fetch = [&](int l, u32x2 (&rw)[LNM_RW][LN_MAXC], f32x4 (&wv)[LN_MAXC]) {
+        const float* w = a.w[l];
+        const bf16_t* dy = a.dy[l];
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            wv[i] = (c < nc) ? *(const f32x4*)(w + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < LNM_RW; ++r) rw[r][i] = (c < nc) ? *(const u32x2*)(dy + roff[r] + c * 4) : u32x2{0u, 0u};
+        }
+    };
+    fetch(a.L - 1, raws, ww);
+    for (int l = a.L - 1; l >= 0; --l) {           // the order of the decoder's backward: last layer first
+        if (l > 0) fetch(l - 1, raws_n, ww_n);
+        f32x4 dwa[LN_MAXC];
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) dwa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < LNM_RW; ++r) {
+            const float live = (row0 + r < a.rows) ? 1.f : 0.f;
+            f32x4 g[LN_MAXC];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < nc) {
+                    const u32x2 raw = raws[r][i];
+                    const f32x4 d = f32x4{bf16_to_f32(raw[0] & 0xffff), bf16_to_f32(raw[0] >> 16), bf16_to_f32(raw[1] & 0xffff), bf16_to_f32(raw[1] >> 16)} * live;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g[i][e] = d[e] * ww[i][e];
+                        dwa[i][e] += d[e] * xh[r][i][e];
+                        s1 += g[i][e];
+                        s2 += g[i][e] * xh[r][i][e];
+                    }
+                }
+            }
+            const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (dx = term_{L-1}, then dx = term_l + dx, like the chained launches: 0 + term is the term)
+                        const float inner = g[i][e] - c1 - xh[r][i][e] * c2;
+                        acc[r][i][e] = (!TAIL || c * 4 + e < D) ? mul_then_add(rs[r], inner, acc[r][i][e]) : acc[r][i][e];   // term rounded first
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            ww[i] = ww_n[i];
+#pragma unroll
+            for (int r = 0; r < LNM_RW; ++r) raws[r][i] = raws_n[r][i];
+        }
+        // this layer's weight-gradient partial row of the workgroup
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) *(f32x4*)(&red[wave][c * 4]) = dwa[i];
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += 256)
+            a.dw_part[((long)blockIdx.x * a.L + l) * D + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+    }
+#pragma unroll
+    for (int r = 0; r < LNM_RW; ++r) {
+        if (row0 + r >= a.rows) break;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nc) {
+                f32x4 o = acc[r][i];
+                if (a.dx_in) {
+                    const f32x4 p_ = *(const f32x4*)(a.dx_in + roff[r] + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = mul_then_add(o[e], 1.0f, p_[e]);
+                }
+                *(f32x4*)(a.dx_out + roff[r] + c * 4) = o;
+                if (a.dx_bf16) *(u32x2*)(a.dx_bf16 + roff[r] + c * 4) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            } else if (c < ncl) {
+                *(f32x4*)(a.dx_out + roff[r] + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.dx_bf16) *(u32x2*)(a.dx_bf16 + roff[r] + c * 4) = u32x2{0u, 0u};
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,6 +829,61 @@ extern "C" int ego_layernorm_bwd(const void* dy, const int* dy_row, const float*
     ColsumDst dst{};
     dst.p[0] = dw; dst.seg = D;
     colsum_launch(work, nwg, D, dst, stream);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+extern "C" int ego_layernorm_fwd_multi(const float* x, int n_layers, const float* const* w, void* const* y, float* mean, float* rstd,
+                                       int rows, int D, long ld, float eps, hipStream_t stream) {
+    if (rows <= 0 || n_layers <= 0) return EGO_OK;
+    if (n_layers > LN_MULTI_MAX || !w || !y || D <= 0 || ld % 4 || ld < D || ld > LN_MAXC_MAX * 256) return EGO_ERR_ARG;
+    LnMultiFwd a{};
+    a.x = x; a.mean = mean; a.rstd = rstd; a.L = n_layers; a.rows = rows; a.D = D; a.ld = (int)ld; a.eps = eps;
+    for (int l = 0; l < n_layers; ++l) { if (!w[l] || !y[l]) return EGO_ERR_ARG; a.w[l] = w[l]; a.y[l] = (bf16_t*)y[l]; }
+#define LNM_FWD_(C, T) EGO_LAUNCH((ln_fwd_multi_kernel<C, T>), dim3((rows + 3) / 4), dim3(256), 0, stream, a)
+#define LNM_FWD(C) do { if (D % 4) LNM_FWD_(C, true); else LNM_FWD_(C, false); } while (0)
+    if (ld <= 768) LNM_FWD(3); else if (ld <= 1024) LNM_FWD(4); else if (ld <= 1536) LNM_FWD(6); else LNM_FWD(8);
+#undef LNM_FWD_
+#undef LNM_FWD
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+namespace {
+int lnm_rows(long) { return 4 * lnm_rw(0); }
+}  // namespace
+
+extern "C" long ego_layernorm_bwd_multi_work_floats(int rows, int D, int n_layers) {
+    // (the partial rows are laid out by the row pitch's kernel instantiation; D <= ld, so size for the smaller workgroups of D itself)
+    const int per = lnm_rows(D);
+    return colsum_work_floats((rows + per - 1) / per, n_layers * D);
+}
+
+extern "C" int ego_layernorm_bwd_multi(int n_layers, const void* const* dy, const float* const* w, float* const* dw, const float* x,
+                                       const float* mean, const float* rstd, const float* dx_in, float* dx_out, void* dx_bf16,
+                                       float* work, long work_floats, int rows, int D, long ld, hipStream_t stream) {
+    if (rows <= 0 || n_layers <= 0) return EGO_OK;
+    if (n_layers > LN_MULTI_MAX || !dy || !w || !dw || D <= 0 || ld % 4 || ld < D || ld > 6 * 256 || !work ||
+        work_floats < ego_layernorm_bwd_multi_work_floats(rows, D, n_layers)) return EGO_ERR_ARG;      // (ld <= 1536: four rows of xhat + dx per lane)
+    LnMultiBwd a{};
+    a.x = x; a.mean = mean; a.rstd = rstd; a.dx_in = dx_in; a.dx_out = dx_out; a.dx_bf16 = (bf16_t*)dx_bf16; a.dw_part = work;
+    a.L = n_layers; a.rows = rows; a.D = D; a.ld = (int)ld;
+    ColsumDst dst{};
+    for (int l = 0; l < n_layers; ++l) {
+        if (!dy[l] || !w[l] || !dw[l]) return EGO_ERR_ARG;
+        a.dy[l] = (const bf16_t*)dy[l]; a.w[l] = w[l]; dst.p[l] = dw[l];
+    }
+    dst.seg = D;
+    const int per = lnm_rows(ld);
+    const int nwg = (rows + per - 1) / per;
+    if (work_floats < colsum_work_floats(nwg, n_layers * D)) return EGO_ERR_ARG;
+#define LNM_BWD_(C, T) EGO_LAUNCH((ln_bwd_multi_kernel<C, T>), dim3(nwg), dim3(256), 0, stream, a)
+#define LNM_BWD(C) do { if (D % 4) LNM_BWD_(C, true); else LNM_BWD_(C, false); } while (0)
+    if (ld <= 768) LNM_BWD(3); else if (ld <= 1024) LNM_BWD(4); else LNM_BWD(6);
+#undef LNM_BWD_
+#undef LNM_BWD
+    LAUNCH_CHECK();
+    colsum_launch(work, nwg, n_layers * D, dst, stream);
     LAUNCH_CHECK();
     return EGO_OK;
 }

@@ -111,6 +111,10 @@ class Engine:
         # decoder self-attention launched by row groups (one interval per workgroup); 0: per-row interval launches (round 3)
         self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
         self.attn_split = os.environ.get("EGOM2P_ATTN_SPLIT", "1") != "0"       # generation path: split keys on under-filled grids
+        # every decoder layer's context_norm normalises the SAME context tensor: one fused launch forward (x and its statistics
+        # read once, one output per layer) and one backward (x once, one write of the context gradient) instead of one per layer
+        self.ctx_ln_fused = (os.environ.get("EGOM2P_CTX_LN_FUSED", "1") != "0" and not self.fp8_forward and self.D <= 1536
+                             and 0 < cfg.decoder_depth <= 32)
 
     def _ring_next(self):
         self._ring_i = (self._ring_i + 1) % len(self.ring_b)
@@ -472,6 +476,8 @@ class Engine:
         self.t_d3 = e(R, D)
         self.dctx = e(RN, D, dt=F32)
         self.dctx_b = e(RN, D)
+        self.st_ctx = e(2, RN, dt=F32)              # statistics of the context rows (one LayerNorm input for all decoder layers)
+        self.dcn = None                             # per-layer gradients of the context_norm outputs (fused backward): allocated on first use
         self.dxe = e(RN, D, dt=F32)                # encoder residual-stream gradient
         self.dxe_b = e(RN, D)
         self.t_d = e(R, D)                         # generic [rows, D] bf16 temp
@@ -683,6 +689,9 @@ class Engine:
                       bias=self.p["decoder_proj_context.bias"])
 
         # ---- decoder (egom2p_model.py:520-523; DecoderBlock.forward egom2p_utils.py:387-391)
+        if self.ctx_ln_fused:
+            ops.layernorm_fwd_multi(self.ctx[:RN], [self.p[f"decoder.{i}.context_norm.weight"] for i in range(cfg.decoder_depth)],
+                                    [w["cn"] for w in self.dec], self.st_ctx[0], self.st_ctx[1], eps=cfg.eps, width=self.Dl)
         for i, w in enumerate(self.dec):
             pre = f"decoder.{i}"
             nxt = self.dec[i + 1]["x"] if i + 1 < cfg.decoder_depth else self.y_out
@@ -693,7 +702,8 @@ class Engine:
             self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], w["x1"], RM, L.EPI_RESID, R=w["x"])
             self._ln(w["x1"][:RM], f"{pre}.query_norm.weight", w["qn"], w["stq"])
             self._lin_fwd(f"{pre}.cross_attn.q.weight", w["qn"], w["q"], RM)
-            self._ln(self.ctx[:RN], f"{pre}.context_norm.weight", w["cn"], w["stc"])
+            if not self.ctx_ln_fused:
+                self._ln(self.ctx[:RN], f"{pre}.context_norm.weight", w["cn"], w["stc"])
             self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
             self._attn(w["q"], 0, A, w["kv"], 0, A, 2 * A, w["xo"], w["lse_x"], self.zero_b, ce["n_valid"], 1, 0, B, M, N,
                        o_lo=w["xo_lo"])
@@ -812,6 +822,10 @@ class Engine:
 
         # ---- decoder layers
         first_ctx = True
+        fused = self.ctx_ln_fused
+        if fused and self.dcn is None:
+            self.dcn = [torch.empty(self.Bmax * N, D, device=self.dev, dtype=BF16) for _ in range(cfg.decoder_depth)]
+        held = []                     # decoder buckets whose context_norm weight gradient is still to come (fused backward)
         for i in reversed(range(cfg.decoder_depth)):
             w, pre = self.dec[i], f"decoder.{i}"
             dres_b = self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
@@ -825,15 +839,29 @@ class Engine:
             ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
                               self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=nb, width=self.Dl)
             dres_b = nb
-            dcn = self.t_d3            # not t_d2: dq is still being read by the q-projection wgrad on the side stream
+            dcn = self.dcn[i] if fused else self.t_d3    # not t_d2: dq is still being read by the q-projection wgrad on the side stream
             self._lin_bwd(f"{pre}.cross_attn.kv.weight", dkv, w["cn"], dcn, RN)
-            ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
-                              self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
+            if not fused:
+                ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
+                                  self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
             first_ctx = False
             dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"], groups=self._dec_groups())
-            done(pre)
+            if fused:
+                held.append(pre)
+            else:
+                done(pre)
         if cfg.decoder_depth == 0:
             self.dctx[:RN].zero_()
+        elif fused:
+            # all layers' context_norm backward in one launch: the context and its statistics are read once, the context gradient
+            # is written once (fp32 + the bf16 copy the context projection's backward reads) - summed in the chained launches'
+            # order, bit for bit their result; only now are the decoder layers' gradient buckets complete
+            Ld = cfg.decoder_depth
+            ops.layernorm_bwd_multi([self.dcn[i][:RN] for i in range(Ld)], self.ctx[:RN], self.st_ctx[0], self.st_ctx[1],
+                                    [self.p[f"decoder.{i}.context_norm.weight"] for i in range(Ld)], self.dctx[:RN],
+                                    [self.g[f"decoder.{i}.context_norm.weight"] for i in range(Ld)], dx_bf16=self.dctx_b[:RN], width=self.Dl)
+            for pre in held:
+                done(pre)
         # decoder input embeddings: mask token + (pos + mod_emb)
         dmods = self.dmods
         ops.embed_bwd(None, [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods], self.g["mask_token"],
@@ -841,7 +869,8 @@ class Engine:
         done("head")
 
         # ---- context projection + encoder_norm
-        ops.cast_f32_bf16(self.dctx[:RN], self.dctx_b)
+        if not (fused and cfg.decoder_depth > 0):
+            ops.cast_f32_bf16(self.dctx[:RN], self.dctx_b)
         ops.bias_grad(self.dctx_b, RN, D, self.g["decoder_proj_context.bias"])
         dxe_n = self.t_d
         self._lin_bwd("decoder_proj_context.weight", self.dctx_b, self.xe, dxe_n, RN)

@@ -60,6 +60,30 @@ def layernorm_bwd(dy, x, mean, rstd, w, dx_out, dw, dx_in=None, dx_bf16=None, dy
                                 _p(dx_bf16), _p(dw), _p(wk), wk.numel(), rows, D, ld, _stream()), "ego_layernorm_bwd")
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def layernorm_fwd_multi(x, ws, ys, mean, rstd, eps=1e-6, width=None):
+    """ys[l] = bf16(LN(x) * ws[l]) for every l in one pass over x (the decoder's per-layer context_norm of the same context)"""
+    _need_cuda(x)
+    rows, ld = x.shape
+    D = ld if width is None else width
+    check(L.load().ego_layernorm_fwd_multi(_p(x), len(ws), _ptr_array(ws), _ptr_array(ys), _p(mean), _p(rstd), rows, D, ld, eps, _stream()),
+          "ego_layernorm_fwd_multi")
+
+
+def layernorm_bwd_multi(dys, x, mean, rstd, ws, dx_out, dws, dx_in=None, dx_bf16=None, width=None):
+    """dx_out = (dx_in) + sum_l LN-backward(dys[l]; ws[l]), dws[l] += the layers' weight gradients: x is read once"""
+    _need_cuda(x)
+    rows, ld = x.shape
+    D = ld if width is None else width
+    lib = L.load()
+    wk = _work(x.device, lib.ego_layernorm_bwd_multi_work_floats(rows, D, len(ws)))
+    check(lib.ego_layernorm_bwd_multi(len(ws), _ptr_array(dys), _ptr_array(ws), _ptr_array(dws), _p(x), _p(mean), _p(rstd), _p(dx_in),
+                                      _p(dx_out), _p(dx_bf16), _p(wk), wk.numel(), rows, D, ld, _stream()), "ego_layernorm_bwd_multi")
+
+
 def gemm_nt(A, B, C_out, M, N, K, epi=L.EPI_BF16, R=None, bias=None, m_range=None, lda=None, ldb=None, ldc=None, ldr=None):
     """C[M,N] = A[M,K] @ B[N,K]^T (+ epilogue)."""
     _need_cuda(A)

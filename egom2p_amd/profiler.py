@@ -107,6 +107,13 @@ class KernelTimer:
             n = x.shape[0] * x.shape[1]
             return 0.0, n * (2.0 + 4.0 + 4.0 + (4.0 if dx_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0))
 
+        def c_ln_fwd_multi(x, ws, ys, mean, rstd, eps=1e-6, width=None):
+            return 0.0, x.shape[0] * x.shape[1] * (4.0 + 2.0 * len(ws))
+
+        def c_ln_bwd_multi(dys, x, mean, rstd, ws, dx_out, dws, dx_in=None, dx_bf16=None, width=None):
+            n = x.shape[0] * x.shape[1]
+            return 0.0, n * (4.0 + 2.0 * len(ws) + 4.0 + (4.0 if dx_in is not None else 0.0) + (2.0 if dx_bf16 is not None else 0.0))
+
         def c_swiglu_fwd(ab, h, rows, F):
             return 0.0, rows * F * 6.0
 
@@ -135,7 +142,7 @@ class KernelTimer:
         table = {
             "gemm_nt_fp8": c_gemm_nt_fp8, "gemm_nt_swiglu_fwd_fp8": c_gemm_nt_swiglu_fwd_fp8, "quant_fp8_rows": c_quant,
             "gemm_nt": c_gemm_nt, "gemm_nt_swiglu_bwd": c_gemm_nt_swiglu_bwd, "gemm_nt_swiglu_fwd": c_gemm_nt_swiglu_fwd, "gemm_tn": c_gemm_tn, "attn_fwd": c_attn_fwd, "attn_bwd": c_attn_bwd,
-            "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
+            "layernorm_fwd": c_ln_fwd, "layernorm_bwd": c_ln_bwd, "layernorm_fwd_multi": c_ln_fwd_multi, "layernorm_bwd_multi": c_ln_bwd_multi, "swiglu_fwd": c_swiglu_fwd, "swiglu_bwd": c_swiglu_bwd,
             "ce_fwd": c_ce, "ce_bwd": c_ce_bwd, "ce_fwd_bwd": c_ce_bwd,          # fused: one read + one write of the logits
         }
         # HBM-bound front-end / bookkeeping kernels: algorithmic bytes (the index streams once, only

@@ -276,6 +276,20 @@ typedef struct {
 } ego_budget_desc;
 int ego_budget_dirichlet(const ego_budget_desc* d, const void* clip_keys, int B, int* k_in, int* k_tgt, hipStream_t stream);
 
+/* One input, n_layers LayerNorms: the decoder's `context_norm` of every layer normalises the same context tensor with its own
+ * weight (egom2p_utils.py:387-391 per DecoderBlock, egom2p_model.py:520-521).  Forward: x and its statistics are read /
+ * formed once, y[l] = bf16(LN(x) * w[l]) for every layer (bitwise ego_layernorm_fwd's rows).  Backward: x once, the upstream
+ * gradients dy[l] once each, dx_out = (dx_in) + sum_l LN-backward_l - summed in the order l = n_layers-1 .. 0 like the chained
+ * ego_layernorm_bwd calls (bit for bit their dx) - and dw[l] += the layer's weight gradient (ordered column sums: bitwise
+ * reproducible, not bitwise the chained calls' - the partial rows are cut differently).  w / y / dy / dw: HOST arrays of
+ * n_layers device pointers (n_layers <= 32).  Backward: ld <= 1536. */
+int ego_layernorm_fwd_multi(const float* x, int n_layers, const float* const* w, void* const* y, float* mean, float* rstd, int rows,
+                            int D, long ld, float eps, hipStream_t stream);
+long ego_layernorm_bwd_multi_work_floats(int rows, int D, int n_layers);
+int ego_layernorm_bwd_multi(int n_layers, const void* const* dy, const float* const* w, float* const* dw, const float* x,
+                            const float* mean, const float* rstd, const float* dx_in, float* dx_out, void* dx_bf16, float* work,
+                            long work_floats, int rows, int D, long ld, hipStream_t stream);
+
 /* ---- loss head ------------------------------------------------------------------------------- */
 
 /* F.cross_entropy(reduction='mean') per modality over bf16 logits rows [range[0], range[0]+range[1])

@@ -604,6 +604,57 @@ def test_layernorm(rows, D):
 
 
 # ------------------------------------------------------------------------------------------ swiglu / casts / CE
+@pytest.mark.parametrize("rows,D,ld,Lyr", [(1000, 768, 768, 12), (37, 128, 128, 3), (513, 1152, 1152, 24), (130, 1020, 1024, 2), (64, 126, 128, 1)])
+def test_layernorm_one_input_many_layers(rows, D, ld, Lyr):
+    """ego_layernorm_fwd_multi / _bwd_multi (the decoder's per-layer context_norm of one context tensor) against the chained
+    single-layer calls: outputs, statistics and dx bit for bit (same expressions, same order of the layer sum), the weight
+    gradients to fp32 round-off (their partial rows are cut differently), padded pitches included; and against fp32 torch."""
+    x = torch.zeros(rows, ld, device=DEV)
+    x[:, :D] = torch.randn(rows, D, device=DEV) * 2 + 0.3
+    ws = [torch.rand(D, device=DEV) + 0.5 for _ in range(Lyr)]
+    dys = []
+    for _ in range(Lyr):
+        d = torch.zeros(rows, ld, device=DEV)
+        d[:, :D] = torch.randn(rows, D, device=DEV)
+        dys.append(_bf(d))
+    # chained single-layer calls (decoder order: last layer first in the backward)
+    ys1 = [torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(Lyr)]
+    mean1, rstd1 = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    for l in range(Lyr):
+        ops.layernorm_fwd(x, ws[l], ys1[l], mean1, rstd1, width=D)
+    dx1, dxb1 = torch.empty(rows, ld, device=DEV), torch.empty(rows, ld, device=DEV, dtype=torch.bfloat16)
+    dws1 = [torch.full((D,), 0.25, device=DEV) for _ in range(Lyr)]
+    for k, l in enumerate(reversed(range(Lyr))):
+        ops.layernorm_bwd(dys[l], x, mean1, rstd1, ws[l], dx1, dws1[l], dx_in=None if k == 0 else dx1, dx_bf16=dxb1, width=D)
+    # fused
+    ys2 = [torch.full((rows, ld), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(Lyr)]
+    mean2, rstd2 = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd_multi(x, ws, ys2, mean2, rstd2, width=D)
+    dx2, dxb2 = torch.full((rows, ld), 9.0, device=DEV), torch.full((rows, ld), 9.0, device=DEV, dtype=torch.bfloat16)
+    dws2 = [torch.full((D,), 0.25, device=DEV) for _ in range(Lyr)]
+    ops.layernorm_bwd_multi(dys, x, mean2, rstd2, ws, dx2, dws2, dx_bf16=dxb2, width=D)
+    torch.cuda.synchronize()
+    assert torch.equal(mean1, mean2) and torch.equal(rstd1, rstd2)
+    for l in range(Lyr):
+        assert torch.equal(ys1[l], ys2[l]), l
+        assert _rel(dws2[l] - 0.25, dws1[l] - 0.25) < 1e-5, l
+    assert torch.equal(dx1, dx2) and torch.equal(dxb1, dxb2)
+    # fp32 torch reference of the sum of the layers' LayerNorm backward
+    xr = x[:, :D].clone().requires_grad_(True)
+    tot = 0
+    for l in range(Lyr):
+        yl = torch.nn.functional.layer_norm(xr, (D,), ws[l], None, 1e-6)
+        tot = tot + (yl * dys[l][:, :D].float()).sum()
+    tot.backward()
+    assert _rel(dx2[:, :D], xr.grad) < 1e-5
+    assert not dx2[:, D:].any()
+    # accumulate on top of an existing gradient (dx_in)
+    base = torch.randn(rows, ld, device=DEV)
+    dx3 = torch.empty(rows, ld, device=DEV)
+    ops.layernorm_bwd_multi(dys, x, mean2, rstd2, ws, dx3, [torch.zeros(D, device=DEV) for _ in range(Lyr)], dx_in=base, width=D)
+    assert _rel(dx3[:, :D], (dx2 + base)[:, :D]) < 1e-6
+
+
 def test_swiglu():
     rows, F = 777, 2048
     ab = _bf(torch.randn(rows, 2 * F, device=DEV))
