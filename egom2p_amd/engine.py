@@ -18,6 +18,7 @@ Layout decisions (MI355X-first, 288 GB HBM):
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -82,13 +83,20 @@ class Engine:
                 # A = H * 64 is the N / K extent of the qkv / proj GEMMs and the pitch of the [rows, A] buffers: the kernels are
                 # validated for multiples of 128 only (an odd head count, e.g. dim 960 = 15 x 64, would need padded heads)
                 raise L.EgoHipError(f"heads of 64 need an even head count (dim={cfg.dim}, heads={cfg.num_heads}: A = {self.H * 64} is not a multiple of 128)")
-        else:
-            fits = [h for h in (96, 128) if h >= self.HD and (self.H * h) % 128 == 0]
+        self.Hs = self.H                      # heads in storage: >= H (all-zero phantom heads make A a multiple of 128)
+        if self.HD != 64:
+            # (pad, stored heads) with the narrowest rows: the registered ego-L (15 heads of 68) is 16 x 96 = 1536 wide - one
+            # all-zero phantom head (q = k = v = 0: uniform softmax over zero values, output and every gradient exactly 0)
+            # costs 1/16 of the attention work, 15 x 128 = 1920 cost 25 % of it and of the qkv / proj GEMMs.
+            # EGOM2P_HEAD_PAD=128 keeps the round-3 layout.
+            pads = [h for h in (96, 128) if h >= self.HD and h >= int(os.environ.get("EGOM2P_HEAD_PAD", "0"))]
+            fits = sorted((next(n for n in range(self.H, self.H + 9) if (n * h) % 128 == 0) * h, h) for h in pads)
             if not fits:
                 raise L.EgoHipError(f"no storage layout for dim={cfg.dim}, heads={cfg.num_heads} x {self.HD}")
-            self.HDP = fits[0]
-        self.A = self.H * self.HDP
-        self.padded = self.D != self.Dl or self.HDP != self.HD
+            self.HDP = fits[0][1]
+            self.Hs = fits[0][0] // self.HDP
+        self.A = self.Hs * self.HDP
+        self.padded = self.D != self.Dl or self.HDP != self.HD or self.Hs != self.H
         if self.padded and fp8_forward:
             raise L.EgoHipError("the fp8 forward is built for the unpadded shapes (dim % 128 == 0, head_dim 64)")
         self.F, self.Fp = cfg.mlp_hidden, _pad128(cfg.mlp_hidden)
@@ -106,11 +114,11 @@ class Engine:
         # optional: weight-gradient GEMMs on a side stream beside the dgrad / attention chain of the same layer, joined
         # at every bucket boundary.  Measured on MI355X: parity-clean but 5 % SLOWER than one stream (the co-running
         # kernels fight for LDS / L2), so it is off by default (EGOM2P_WGRAD_STREAM=1 enables it).
-        import os
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("EGOM2P_WGRAD_STREAM", "0") == "1" else None
         # decoder self-attention launched by row groups (one interval per workgroup); 0: per-row interval launches (round 3)
         self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
         self.attn_split = os.environ.get("EGOM2P_ATTN_SPLIT", "1") != "0"       # generation path: split keys on under-filled grids
+        self.cfg_pair = os.environ.get("EGOM2P_CFG_PAIR", "1") != "0"           # guided step: cond + uncond share one decoder pass
         # every decoder layer's context_norm normalises the SAME context tensor: one fused launch forward (x and its statistics
         # read once, one output per layer) and one backward (x once, one write of the context gradient) instead of one per layer
         self.ctx_ln_fused = (os.environ.get("EGOM2P_CTX_LN_FUSED", "1") != "0" and not self.fp8_forward and self.D <= 1536
@@ -264,7 +272,7 @@ class Engine:
         zero padding.  Unpadded configurations: the tensor itself (fc1 / fc3 / fc2: without the F -> Fp pad).  Padded ones:
         the model-dim axes cut to cfg.dim and the head axis split so that every head loses its pad columns - a strided view
         of as many elements as the reference tensor, in its element order (`.reshape(reference shape)` gives the tensor)."""
-        F, Dl, H, HD, HDP = self.F, self.Dl, self.H, self.HD, self.HDP
+        F, Dl, H, Hs, HD, HDP = self.F, self.Dl, self.H, self.Hs, self.HD, self.HDP
         if key.endswith("mlp.fc1.weight") or key.endswith("mlp.fc3.weight"):
             return t[:F, :Dl]
         if key.endswith("mlp.fc2.weight"):
@@ -274,13 +282,13 @@ class Engine:
         if t.dim() == 1:
             return t[:Dl]
         if key.endswith("qkv.weight"):
-            return t.view(3, H, HDP, self.D)[:, :, :HD, :Dl]
+            return t.view(3, Hs, HDP, self.D)[:, :H, :HD, :Dl]
         if key.endswith("cross_attn.kv.weight"):
-            return t.view(2, H, HDP, self.D)[:, :, :HD, :Dl]
+            return t.view(2, Hs, HDP, self.D)[:, :H, :HD, :Dl]
         if key.endswith("cross_attn.q.weight"):
-            return t.view(H, HDP, self.D)[:, :HD, :Dl]
+            return t.view(Hs, HDP, self.D)[:H, :HD, :Dl]
         if key.endswith("proj.weight"):                       # attn.proj / self_attn.proj / cross_attn.proj: [D, A]
-            return t.view(self.D, H, HDP)[:Dl, :, :HD]
+            return t.view(self.D, Hs, HDP)[:Dl, :H, :HD]
         if key == "decoder_proj_context.weight":
             return t[:Dl, :Dl]
         return t[:, :Dl]                                      # token tables, to_logits: [V, D]
@@ -414,7 +422,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ workspaces
     def _alloc_workspaces(self):
-        B, N, M, D, A, Fp, H = self.Bmax, self.N, self.M, self.D, self.A, self.Fp, self.H
+        B, N, M, D, A, Fp, H = self.Bmax, self.N, self.M, self.D, self.A, self.Fp, self.Hs
         dev, cfg = self.dev, self.cfg
         RN, RM = B * N, B * M
 
@@ -573,7 +581,7 @@ class Engine:
         A = self.A
         ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, lse, ks, ke, r_bs, r_rs,
-                     B, self.H, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP,
+                     B, self.Hs, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP,
                      seg=seg, seg_bad=seg_bad)
 
     # generation path: under-filled attention grids (1707 decoder rows x 12 heads = 168 workgroups on 256 CUs, each walking every
@@ -581,7 +589,7 @@ class Engine:
     SPLIT_TARGET_WGS = 640
 
     def _kv_splits(self, B, Nq, Nk):
-        base = B * self.H * ((Nq + 127) // 128)
+        base = B * self.Hs * ((Nq + 127) // 128)
         if self.HDP != 64 or base <= 0 or not self.attn_split:
             return 1
         s = min(8, self.SPLIT_TARGET_WGS // base, ((Nk + 63) // 64) // 4)       # at least four 64-key tiles per run
@@ -592,10 +600,10 @@ class Engine:
         A = self.A
         sp = self._kv_splits(B, Nq, Nk)
         ws = w.get("att_ws")
-        if sp > 1 and ws is not None and ws.numel() >= ops.attn_fwd_split_floats(B, self.H, Nq, sp):
+        if sp > 1 and ws is not None and ws.numel() >= ops.attn_fwd_split_floats(B, self.Hs, Nq, sp):
             ops.attn_fwd_split(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                                kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, w["lse"], ks, ke, 1, 0,
-                               B, self.H, Nq, Nk, self.scale, sp, ws)
+                               B, self.Hs, Nq, Nk, self.scale, sp, ws)
         else:
             self._attn(q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, w["lse"], ks, ke, 1, 0, B, Nq, Nk)
 
@@ -613,7 +621,7 @@ class Engine:
         ops.attn_bwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, do_t.data_ptr(), Nq * A, A,
                      lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
-                     kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.H, Nq, Nk, self.scale,
+                     kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.Hs, Nq, Nk, self.scale,
                      o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP, seg=seg, seg_bad=seg_bad)
 
     # ------------------------------------------------------------------------------------ forward
@@ -925,37 +933,129 @@ class Engine:
         self._iw, self._infer_key = None, None
 
     # ------------------------------------------------------------------------------------ generation (config 4)
-    def _alloc_infer(self, B: int, Nmax: int, Mmax: int, fresh: bool = False):
+    def _alloc_infer(self, B: int, Nmax: int, Mmax: int, fresh: bool = False, groups: int = 1):
         """One set of buffers (nothing is saved for a backward) for encoder-decoder passes of the ROAR / CFG
-        generation path, sized for up to Nmax encoder rows and Mmax decoder rows per sample."""
-        key = (B, Nmax, Mmax)
-        if not fresh and self._infer_key is not None and all(a >= b for a, b in zip(self._infer_key, key)):
+        generation path, sized for up to Nmax encoder rows and Mmax decoder rows per sample.  groups = 2: the conditional
+        and the unconditional pass of one guided step share ONE decoder pass (`infer_logits_cfg`) - decoder buffers hold
+        2 B samples, context buffers the two contexts one after the other."""
+        G = int(groups)
+        key = (G, B, Nmax, Mmax)
+        if not fresh and self._infer_key is not None and self._infer_key[0] >= G and all(a >= b for a, b in zip(self._infer_key[1:], key[1:])):
             return self._iw
-        D, A, Fp, H, dev = self.D, self.A, self.Fp, self.H, self.dev
-        R = B * max(Nmax, Mmax)
+        D, A, Fp, H, dev = self.D, self.A, self.Fp, self.Hs, self.dev
+        RE, RD, RC = B * Nmax, G * B * Mmax, G * B * Nmax         # encoder rows of one pass, decoder rows, context rows
+        R = max(RE, RD)
 
         def e(*shape, dt=BF16):
             return torch.empty(*shape, device=dev, dtype=dt)
 
+        def side():
+            return dict(ids_keep=e(B, Nmax, dt=torch.int64), pad=e(B, Nmax, dt=torch.uint8), mod_mask=e(B, Nmax, dt=torch.int16),
+                        slot=e(B, Nmax, dt=I32), local=e(B, Nmax, dt=I32), tok=e(B, Nmax, dt=I32), ks=e(B, Nmax, dt=I32),
+                        ke=e(B, Nmax, dt=I32), n_valid=torch.zeros(B, device=dev, dtype=I32), seg=e(B, self.n_mods, 2, dt=I32),
+                        err=torch.zeros(1, device=dev, dtype=I32))
+
         w = dict(
-            side=dict(ids_keep=e(B, Nmax, dt=torch.int64), pad=e(B, Nmax, dt=torch.uint8), mod_mask=e(B, Nmax, dt=torch.int16),
-                      slot=e(B, Nmax, dt=I32), local=e(B, Nmax, dt=I32), tok=e(B, Nmax, dt=I32), ks=e(B, Nmax, dt=I32),
-                      ke=e(B, Nmax, dt=I32), n_valid=torch.zeros(B, device=dev, dtype=I32), seg=e(B, self.n_mods, 2, dt=I32),
-                      err=torch.zeros(1, device=dev, dtype=I32)),
-            xa=e(R, D, dt=F32), xb=e(R, D, dt=F32), emb=e(B * Nmax, D, dt=F32), ctx=e(B * Nmax, D, dt=F32),
-            ya=e(B * Mmax, D, dt=F32), yb=e(B * Mmax, D, dt=F32),
-            ln=e(R, D), qkv=e(R, 3 * A), ao=e(R, A), ab=e(R, 2 * Fp), h=e(R, Fp), q=e(B * Mmax, A), cn=e(B * Nmax, D),
-            kv=e(B * Nmax, 2 * A), st=e(2, R, dt=F32), lse=e(B, H, max(Nmax, Mmax), dt=F32),
-            zero_b=torch.zeros(B, device=dev, dtype=I32), full_m=torch.zeros(B, device=dev, dtype=I32),
-            dslot=torch.zeros(B * Mmax, device=dev, dtype=I32), dtok=torch.zeros(B * Mmax, device=dev, dtype=I32),
+            groups=G, sides=[side() for _ in range(G)],
+            xa=e(RE, D, dt=F32), xb=e(RE, D, dt=F32), emb=e(RE, D, dt=F32), ctx=e(RC, D, dt=F32),
+            ya=e(RD, D, dt=F32), yb=e(RD, D, dt=F32),
+            ln=e(max(R, RC), D), qkv=e(R, 3 * A), ao=e(R, A), ab=e(R, 2 * Fp), h=e(R, Fp), q=e(RD, A), cn=e(RC, D),
+            kv=e(RC, 2 * A), st=e(2, max(R, RC), dt=F32), lse=e(G * B, H, max(Nmax, Mmax), dt=F32),
+            zero_b=torch.zeros(G * B, device=dev, dtype=I32), full_m=torch.zeros(G * B, device=dev, dtype=I32),
+            dslot=torch.zeros(RD, device=dev, dtype=I32), dtok=torch.zeros(RD, device=dev, dtype=I32),
         )
-        # scratch of the split-key attention launches: only query-row counts whose grid is under-filled ever use it
-        rows_split = min(max(Nmax, Mmax), 128 * max(1, self.SPLIT_TARGET_WGS // (2 * B * H)))
-        w["att_ws"] = (e(8 * B * H * rows_split * 66, dt=F32) if (self.HDP == 64 and self.attn_split and B * H * ((rows_split + 127) // 128) * 2 <= self.SPLIT_TARGET_WGS)
-                       else None)
+        w["side"] = w["sides"][0]
+        # every decoder layer's context_norm output from one pass over the context (ego_layernorm_fwd_multi)
+        w["cns"] = [e(RC, D) for _ in range(self.cfg.decoder_depth)] if self.ctx_ln_fused else None
+        # scratch of the split-key attention launches: splits x B x H x ceil(Nq / 128) <= SPLIT_TARGET_WGS bounds it
+        w["att_ws"] = e(self.SPLIT_TARGET_WGS * 128 * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split) else None
         if not fresh:
             self._iw, self._infer_key = w, key
         return w
+
+    def _infer_context(self, w, side, enc_inputs, N: int, B: int, ctx: torch.Tensor):
+        """Encoder half of a generation pass: compaction of the unmasked inputs, embeddings, encoder blocks,
+        decoder_proj_context (+ embeddings) -> ctx [B * N, D] fp32 (forward_mask_encoder_generation + encoder,
+        egom2p/models/generate.py:747-757)."""
+        cfg, D, A = self.cfg, self.D, self.A
+        mods = [m for m in self.mods if m.name in enc_inputs]
+        RN = B * N
+        ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
+                    None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
+        x, xn = w["xa"], w["xb"]
+        ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
+                      [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
+                      x, w["emb"], RN, D)
+        for i in range(cfg.encoder_depth):
+            pre = f"encoder.{i}"
+            self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
+            self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
+            self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], side["n_valid"], B, N, N)
+            self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
+            self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
+            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
+        self._ln(x[:RN], "encoder_norm.weight", w["ln"], w["st"])
+        self._lin_fwd("decoder_proj_context.weight", w["ln"], ctx, RN, L.EPI_BIAS_RESID, R=w["emb"],
+                      bias=self.p["decoder_proj_context.bias"])
+
+    def _infer_decode(self, w, parts, target: str, dec_pos: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+        """Decoder half of a generation pass over len(parts) groups of B samples that decode the SAME positions against
+        different contexts (parts[g] = (side, N_g, first context row); groups with an empty context last).  Everything
+        but the cross-attention itself is one launch for all groups.  Returns bf16 logits [groups * B * M, V]."""
+        cfg, D, A = self.cfg, self.D, self.A
+        tm = {m.name: m for m in self.mods}[target]
+        B, M = dec_pos.shape
+        G = len(parts)
+        RM, RD = B * M, G * B * M
+        RC = sum(B * n for _, n, _ in parts)
+        n_ctx = sum(1 for _, n, _ in parts if n > 0)
+        if any(n > 0 for _, n, _ in parts[n_ctx:]):
+            raise ValueError("groups with an empty context come last")
+        RQ = n_ctx * RM                                     # decoder rows that have a context to attend to
+        # decoder rows: mask token + positional + modality embedding of the selected target positions (:481-516)
+        y, yn = w["ya"], w["yb"]
+        local = dec_pos.to(self.dev, I32)
+        local = (local.unsqueeze(0).expand(G, B, M) if G > 1 else local).contiguous()
+        ops.embed_fwd(None, [self.pos[tm.name]], [self.p[f"encoder_embeddings.{tm.name}.mod_emb"]], self.p["mask_token"],
+                      w["dslot"], local, w["dtok"], y, None, RD, D)
+        w["full_m"].fill_(M)
+        fused = self.ctx_ln_fused and w.get("cns") is not None and RC > 0
+        if fused:
+            ops.layernorm_fwd_multi(w["ctx"][:RC], [self.p[f"decoder.{i}.context_norm.weight"] for i in range(cfg.decoder_depth)],
+                                    w["cns"], w["st"][0], w["st"][1], eps=cfg.eps, width=self.Dl)
+        for i in range(cfg.decoder_depth):
+            pre = f"decoder.{i}"
+            self._ln(y[:RD], f"{pre}.norm1.weight", w["ln"], w["st"])
+            self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RD)
+            self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], w["full_m"], G * B, M, M)
+            self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RD, L.EPI_RESID, R=y)
+            if RQ > 0:
+                self._ln(yn[:RQ], f"{pre}.query_norm.weight", w["ln"], w["st"])
+                self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RQ)
+                cn = w["cns"][i] if fused else w["cn"]
+                if not fused:
+                    self._ln(w["ctx"][:RC], f"{pre}.context_norm.weight", cn, w["st"])
+                self._lin_fwd(f"{pre}.cross_attn.kv.weight", cn, w["kv"], RC)
+                for g, (side, n, c0) in enumerate(parts[:n_ctx]):
+                    self._attn_infer(w, w["q"], g * RM * A, A, w["kv"], c0 * 2 * A, c0 * 2 * A + A, 2 * A, w["ao"][g * RM:], w["zero_b"],
+                                     side["n_valid"], B, M, n)
+                self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RQ, L.EPI_RESID, R=yn)
+                if RQ < RD:
+                    y[RQ:RD].copy_(yn[RQ:RD])
+            else:
+                # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the
+                # bias-free proj keeps it 0, so the cross-attention residual is the identity
+                y, yn = yn, y
+            self._ln(y[:RD], f"{pre}.norm2.weight", w["ln"], w["st"])
+            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RD)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RD, L.EPI_RESID, R=y)
+            y, yn = yn, y
+        self._ln(y[:RD], "decoder_norm.weight", w["ln"], w["st"])
+        l = self.lin[self.logit_key[tm.name]]
+        logits = out if out is not None else torch.empty(RD, tm.vocab_size, device=self.dev, dtype=BF16)
+        ops.gemm_nt(w["ln"], l.wb, logits, RD, tm.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=tm.vocab_size)
+        return logits
 
     @torch.no_grad()
     def infer_logits(self, enc_inputs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], n_enc: int, target: str,
@@ -968,67 +1068,62 @@ class Engine:
         ROAR order; decoder self-attention is unmasked, sa_mask=None at :761).  Returns bf16 logits [B, M, V]."""
         if self.weights_dirty:
             self.refresh_weights()
-        cfg, D, A, Fp, H = self.cfg, self.D, self.A, self.Fp, self.H
-        byname = {m.name: m for m in self.mods}
-        mods = [m for m in self.mods if m.name in enc_inputs]
-        tm = byname[target]
         B, M = dec_pos.shape
         N = int(n_enc)
         w = ws if ws is not None else self._alloc_infer(B, max(N, 1), M)
-        side = w["side"]
-        RN, RM = B * N, B * M
-        x = None
+        side = w["sides"][0]
         if N > 0:
-            ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
-                        None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
-            x, xn = w["xa"], w["xb"]
-            ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
-                          [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
-                          x, w["emb"], RN, D)
-            for i in range(cfg.encoder_depth):
-                pre = f"encoder.{i}"
-                self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
-                self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
-                self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], side["n_valid"], B, N, N)
-                self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
-                self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
-                self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
-                self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
-            self._ln(x[:RN], "encoder_norm.weight", w["ln"], w["st"])
-            self._lin_fwd("decoder_proj_context.weight", w["ln"], w["ctx"], RN, L.EPI_BIAS_RESID, R=w["emb"],
-                          bias=self.p["decoder_proj_context.bias"])
-        # decoder rows: mask token + positional + modality embedding of the selected target positions (:481-516)
-        y, yn = w["ya"], w["yb"]
-        local = dec_pos.to(self.dev, I32).contiguous()
-        ops.embed_fwd(None, [self.pos[tm.name]], [self.p[f"encoder_embeddings.{tm.name}.mod_emb"]], self.p["mask_token"],
-                      w["dslot"], local, w["dtok"], y, None, RM, D)
-        w["full_m"].fill_(M)
-        for i in range(cfg.decoder_depth):
-            pre = f"decoder.{i}"
-            self._ln(y[:RM], f"{pre}.norm1.weight", w["ln"], w["st"])
-            self._lin_fwd(f"{pre}.self_attn.qkv.weight", w["ln"], w["qkv"], RM)
-            self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], w["full_m"], B, M, M)
-            self._lin_fwd(f"{pre}.self_attn.proj.weight", w["ao"], yn, RM, L.EPI_RESID, R=y)
-            if N > 0:
-                self._ln(yn[:RM], f"{pre}.query_norm.weight", w["ln"], w["st"])
-                self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RM)
-                self._ln(w["ctx"][:RN], f"{pre}.context_norm.weight", w["cn"], w["st"])
-                self._lin_fwd(f"{pre}.cross_attn.kv.weight", w["cn"], w["kv"], RN)
-                self._attn_infer(w, w["q"], 0, A, w["kv"], 0, A, 2 * A, w["ao"], w["zero_b"], side["n_valid"], B, M, N)
-                self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RM, L.EPI_RESID, R=yn)
-            else:
-                # empty context: softmax over zero keys contributes nothing (attn @ v over an empty axis = 0) and the
-                # bias-free proj keeps it 0, so the cross-attention residual is the identity
-                y, yn = yn, y
-            self._ln(y[:RM], f"{pre}.norm2.weight", w["ln"], w["st"])
-            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RM)
-            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RM, L.EPI_RESID, R=y)
-            y, yn = yn, y
-        self._ln(y[:RM], "decoder_norm.weight", w["ln"], w["st"])
-        l = self.lin[self.logit_key[tm.name]]
-        logits = out if out is not None else torch.empty(RM, tm.vocab_size, device=self.dev, dtype=BF16)
-        ops.gemm_nt(w["ln"], l.wb, logits, RM, tm.vocab_size, D, L.EPI_BF16, lda=D, ldb=D, ldc=tm.vocab_size)
-        return logits.view(B, M, tm.vocab_size)
+            self._infer_context(w, side, enc_inputs, N, B, w["ctx"])
+        logits = self._infer_decode(w, [(side, N, 0)], target, dec_pos, out)
+        return logits.view(B, M, -1)
+
+    @torch.no_grad()
+    def infer_logits_cfg(self, enc_cond, n_cond: int, enc_uncond, n_uncond: int, target: str, dec_pos: torch.Tensor,
+                         out: Optional[torch.Tensor] = None, ws: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The conditional and the unconditional pass of one classifier-free-guidance step (generate.py:881-905 runs
+        forward_enc_dec_roar_batched twice) with ONE decoder pass: both decode the same positions from the same mask-token
+        rows, only the cross-attention context differs.  Two encoder passes fill one context buffer back to back; the
+        decoder runs 2 B samples per launch (the launches of this path are latency-bound: twice the rows cost the same
+        time) and cross-attends per half.  Returns (logits_cond, logits_uncond), each bf16 [B, M, V]."""
+        if self.weights_dirty:
+            self.refresh_weights()
+        B, M = dec_pos.shape
+        Nc, Nu = int(n_cond), int(n_uncond)
+        if Nc <= 0:
+            raise ValueError("the conditional pass of a guided step has a context")
+        w = ws if ws is not None else self._alloc_infer(B, max(Nc, Nu, 1), M, groups=2)
+        if w["groups"] < 2:
+            raise ValueError("workspace allocated for single passes (groups=1)")
+        sc, su = w["sides"]
+        self._infer_context(w, sc, enc_cond, Nc, B, w["ctx"])
+        if Nu > 0:
+            self._infer_context(w, su, enc_uncond, Nu, B, w["ctx"][B * Nc:])
+        logits = self._infer_decode(w, [(sc, Nc, 0), (su, Nu, B * Nc)], target, dec_pos, out)
+        V = logits.shape[-1]
+        return logits[:B * M].view(B, M, V), logits[B * M:2 * B * M].view(B, M, V)
+
+    def _graphed(self, key, make_state, run):
+        """Capture-once / replay cache of the generation passes: `make_state()` builds the static buffers (a captured
+        graph bakes in device addresses: it owns its workspace for as long as it lives), `run(st)` issues the launches."""
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.pop(key, None)
+        if g is None:
+            # every graph owns a workspace of ~30 KB per row: bound the cache (a ROAR schedule needs 2 x steps shapes;
+            # the least recently used graph and its buffers are released first)
+            while len(graphs) >= self.max_graphs:
+                graphs.pop(next(iter(graphs)))
+            st = make_state()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                           # warm-up (lazy inits happen here, not in the capture)
+                run(st)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run(st)
+            g = (graph, st)
+        graphs[key] = g                                            # most recently used last
+        return g
 
     def infer_logits_graphed(self, enc_inputs, n_enc: int, target: str, dec_pos: torch.Tensor) -> torch.Tensor:
         """`infer_logits` replayed from a captured hipGraph (BASELINE config 4: "hipGraph-captured decode").
@@ -1039,41 +1134,52 @@ class Engine:
             self.refresh_weights()
         B, M = dec_pos.shape
         names = tuple(m.name for m in self.mods if m.name in enc_inputs)
-        key = (B, names, int(n_enc), M, target)
-        graphs = self.__dict__.setdefault("_graphs", {})
-        g = graphs.pop(key, None)
-        if g is not None:
-            graphs[key] = g                                # most recently used last
-        if g is None:
-            # every graph owns a workspace of ~30 KB per row: bound the cache (a ROAR schedule needs 2 x steps shapes;
-            # the least recently used graph and its buffers are released first)
-            while len(graphs) >= self.max_graphs:
-                graphs.pop(next(iter(graphs)))
-            V = {m.name: m for m in self.mods}[target].vocab_size
-            # a captured graph bakes in device addresses: it owns its workspace for as long as it lives
-            st = {"ws": self._alloc_infer(B, max(int(n_enc), 1), M, fresh=True),
-                  "ids": {n: enc_inputs[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names},
-                  "mask": {n: enc_inputs[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names},
-                  "pos": dec_pos.to(self.dev, I32).clone(),
-                  "out": torch.empty(B * M, V, device=self.dev, dtype=BF16)}
-            run = lambda: self.infer_logits({n: (st["ids"][n], st["mask"][n]) for n in names}, n_enc, target, st["pos"], out=st["out"], ws=st["ws"])
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                           # warm-up (lazy inits happen here, not in the capture)
-                run()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                run()
-            g = graphs[key] = (graph, st)
-        graph, st = g
+        V = {m.name: m for m in self.mods}[target].vocab_size
+
+        def make_state():
+            return {"ws": self._alloc_infer(B, max(int(n_enc), 1), M, fresh=True),
+                    "ids": {n: enc_inputs[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names},
+                    "mask": {n: enc_inputs[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names},
+                    "pos": dec_pos.to(self.dev, I32).clone(),
+                    "out": torch.empty(B * M, V, device=self.dev, dtype=BF16)}
+
+        graph, st = self._graphed((B, names, int(n_enc), M, target), make_state,
+                                  lambda st: self.infer_logits({n: (st["ids"][n], st["mask"][n]) for n in names}, n_enc, target, st["pos"],
+                                                               out=st["out"], ws=st["ws"]))
         for n in names:
             st["ids"][n].copy_(enc_inputs[n][0].reshape(B, -1))
             st["mask"][n].copy_(enc_inputs[n][1].reshape(B, -1))
         st["pos"].copy_(dec_pos)
         graph.replay()
-        V = st["out"].shape[1]
         return st["out"].view(B, M, V)
+
+    def infer_logits_cfg_graphed(self, enc_cond, n_cond: int, enc_uncond, n_uncond: int, target: str, dec_pos: torch.Tensor):
+        """`infer_logits_cfg` (both passes of a guided step, one decoder pass) replayed from a captured hipGraph"""
+        if self.weights_dirty:
+            self.refresh_weights()
+        B, M = dec_pos.shape
+        names = tuple(m.name for m in self.mods if m.name in enc_cond)
+        V = {m.name: m for m in self.mods}[target].vocab_size
+        sets = (enc_cond, enc_uncond)
+
+        def make_state():
+            return {"ws": self._alloc_infer(B, max(int(n_cond), int(n_uncond), 1), M, fresh=True, groups=2),
+                    "ids": [{n: e[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names} for e in sets],
+                    "mask": [{n: e[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names} for e in sets],
+                    "pos": dec_pos.to(self.dev, I32).clone(),
+                    "out": torch.empty(2 * B * M, V, device=self.dev, dtype=BF16)}
+
+        graph, st = self._graphed(("cfg", B, names, int(n_cond), int(n_uncond), M, target), make_state,
+                                  lambda st: self.infer_logits_cfg({n: (st["ids"][0][n], st["mask"][0][n]) for n in names}, n_cond,
+                                                                   {n: (st["ids"][1][n], st["mask"][1][n]) for n in names}, n_uncond,
+                                                                   target, st["pos"], out=st["out"], ws=st["ws"]))
+        for k, e in enumerate(sets):
+            for n in names:
+                st["ids"][k][n].copy_(e[n][0].reshape(B, -1))
+                st["mask"][k][n].copy_(e[n][1].reshape(B, -1))
+        st["pos"].copy_(dec_pos)
+        graph.replay()
+        return st["out"][:B * M].view(B, M, V), st["out"][B * M:].view(B, M, V)
 
     @torch.no_grad()
     def forward_logits(self, mod_dict, dec_order=None) -> Dict[str, torch.Tensor]:

@@ -109,8 +109,7 @@ class GenerationSampler:
         self.use_graphs = use_graphs           # replay each encoder-decoder pass from a captured hipGraph
 
     # one encoder-decoder pass (forward_enc_dec_roar_batched, generate.py:747-766) ---------------------
-    def _logits(self, mod_dict, target_mod, mod_pos, n_enc: Optional[int] = None, ws: Optional[dict] = None):
-        """n_enc given: no host sync (the caller knows the kept-row count, e.g. from the schedule); ws: workspace to use."""
+    def _enc_inputs(self, mod_dict, n_enc: Optional[int] = None):
         eng = self.engine
         enc = {}
         for m in eng.mods:
@@ -124,6 +123,12 @@ class GenerationSampler:
         # rows kept by forward_mask_encoder_generation = max unmasked count over the batch (:413-415)
         if n_enc is None:
             n_enc = int(torch.stack([(~v[1]).sum(1) for v in enc.values()]).sum(0).max().item()) if enc else 0
+        return enc, n_enc
+
+    def _logits(self, mod_dict, target_mod, mod_pos, n_enc: Optional[int] = None, ws: Optional[dict] = None):
+        """n_enc given: no host sync (the caller knows the kept-row count, e.g. from the schedule); ws: workspace to use."""
+        eng = self.engine
+        enc, n_enc = self._enc_inputs(mod_dict, n_enc)
         if ws is not None:
             return eng.infer_logits(enc, n_enc, target_mod, mod_pos, ws=ws)
         if self.use_graphs:
@@ -159,15 +164,30 @@ class GenerationSampler:
         if mod_pos is None:
             mod_pos = self.roar_order(d["target_mask"].to(eng.dev), num_select, seed, noise=st.get("noise"), n_dec=st.get("n_dec"))
         mod_pos = mod_pos.to(eng.dev)
-        logits_cond = self._logits(mod_dict, target_mod, mod_pos, n_enc=st.get("n_enc_cond"), ws=st.get("ws"))
-        if static is not None:
-            logits_cond = logits_cond.clone()          # the two passes share one workspace-independent output buffer each
-        logits_uncond = None
-        if guidance_scale != 1.0 and len(conditioning) > 0:
+        guided = guidance_scale != 1.0 and len(conditioning) > 0
+        uncond = None
+        if guided:
             uncond = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in mod_dict.items()}
             for mod in conditioning:
                 uncond = empty_img_modality(uncond, mod)
-            logits_uncond = self._logits(uncond, target_mod, mod_pos, n_enc=st.get("n_enc_uncond"), ws=st.get("ws"))
+        ws = st.get("ws")
+        pair = guided and getattr(eng, "cfg_pair", False) and (ws is None or ws.get("groups", 1) >= 2)
+        logits_uncond = None
+        if pair:
+            # the two passes of a guided step decode the same rows: one decoder pass over both contexts (engine.infer_logits_cfg)
+            enc_c, n_c = self._enc_inputs(mod_dict, st.get("n_enc_cond"))
+            enc_u, n_u = self._enc_inputs(uncond, st.get("n_enc_uncond"))
+            pair = n_c > 0
+        if pair and ws is None and self.use_graphs:
+            logits_cond, logits_uncond = (t.clone() for t in eng.infer_logits_cfg_graphed(enc_c, n_c, enc_u, n_u, target_mod, mod_pos))
+        elif pair:
+            logits_cond, logits_uncond = eng.infer_logits_cfg(enc_c, n_c, enc_u, n_u, target_mod, mod_pos, ws=ws)
+        else:
+            logits_cond = self._logits(mod_dict, target_mod, mod_pos, n_enc=st.get("n_enc_cond"), ws=ws)
+            if static is not None:
+                logits_cond = logits_cond.clone()
+            if guided:
+                logits_uncond = self._logits(uncond, target_mod, mod_pos, n_enc=st.get("n_enc_uncond"), ws=ws)
         B, M, V = logits_cond.shape
         if uniforms is None:
             uniforms = torch.rand(B * M, device=eng.dev)
@@ -249,7 +269,8 @@ class GenerationSampler:
             st = {"in": {n: {k: v.clone() for k, v in flat[n].items()} for n in names},
                   "noise": [torch.zeros(flat[p["target"]]["target_mask"].shape[1], device=eng.dev) for p in plan],
                   "uni": [torch.zeros(B * p["n_dec"], device=eng.dev) for p in plan],
-                  "ws": eng._alloc_infer(B, n_max, m_max, fresh=True), "out": None}
+                  "ws": eng._alloc_infer(B, n_max, m_max, fresh=True,
+                                         groups=2 if (eng.cfg_pair and any(p["guided"] for p in plan)) else 1), "out": None}
 
             def run():
                 md = {n: {k: v.clone() for k, v in st["in"][n].items()} for n in names}

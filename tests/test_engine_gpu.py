@@ -23,11 +23,22 @@ GRAD_TOL = 4e-2         # same for gradients (two bf16 passes)
 
 
 def _setup(case):
+    case, _, head_pad = case.partition("@")              # "L1020@128": the same fixture on the heads-of-128 storage layout
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]
     sd = synth.build_state_dict(cfg, meta["seed"])
     md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
-    eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"])
+    import os
+    old = os.environ.get("EGOM2P_HEAD_PAD")
+    if head_pad:
+        os.environ["EGOM2P_HEAD_PAD"] = head_pad
+    try:
+        eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"])
+    finally:
+        if head_pad:
+            os.environ.pop("EGOM2P_HEAD_PAD") if old is None else os.environ.__setitem__("EGOM2P_HEAD_PAD", old)
+    if head_pad:
+        assert eng.HDP == int(head_pad) and eng.Hs == eng.H
     eng.load_state_dict(sd)
     mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
     return g, meta, cfg, sd, mdg, eng
@@ -45,9 +56,10 @@ def _tap(g, key, t):
 
 
 # L1020 = the REGISTERED ego-L geometry (dim 1020, 15 heads of 68, F = 2720: egom2p_model.py:1080-1092) at 2 + 2 layers: stored in rows
-# of 1024 with heads padded to 128 (engine.py) - the pad columns must stay exact zeros in activations and gradients
-# XL2046 = the registered ego-XL geometry (dim 2046, 31 heads of 66, F = 5456) at 1 + 1 layers, same storage scheme
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020", "XL2046"])
+# of 1024 with 16 heads of 96 (15 padded heads + one all-zero phantom head: engine.py; "@128" = the round-3 layout, 15 heads of 128) -
+# the pad columns must stay exact zeros in activations and gradients
+# XL2046 = the registered ego-XL geometry (dim 2046, 31 heads of 66, F = 5456) at 1 + 1 layers, same storage scheme (32 heads of 96)
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020", "L1020@128", "XL2046"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim

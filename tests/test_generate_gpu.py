@@ -208,6 +208,63 @@ def test_hipgraph_replay_is_bitwise_identical():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n_dec_so_far", [0, 900])
+def test_cfg_pair_pass_matches_two_separate_passes(n_dec_so_far):
+    """`infer_logits_cfg` (the conditional and the unconditional pass of a guided step share one decoder pass of 2 B samples,
+    the two contexts lie back to back) against two `infer_logits` calls - which the reference fixtures above pin: same logits
+    up to the bf16 rounding of a different key split in the self-attention (grids differ), on a batch whose samples keep
+    different numbers of inputs; the first step's EMPTY unconditional context (cross-attention = identity on that half);
+    and the captured-graph form, bit for bit."""
+    cfg = MODEL_CFGS["ego_b_2e_2d"]
+    eng = Engine(cfg, "cuda:0", max_batch=2, n_enc=64, n_dec=64)
+    eng.init_random(9)
+    B, M = 2, 700
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rgb = synth.randint("pair.rgb", (B, 5120), 64000, seed=1).to(DEV)
+    dep = synth.randint("pair.depth", (B, 5120), 64000, seed=2).to(DEV)
+    m_rgb = torch.zeros(B, 5120, dtype=torch.bool)
+    m_rgb[0, torch.randperm(5120, generator=g)[:1120]] = True          # sample 0 keeps 4000 rgb tokens, sample 1 keeps 3600
+    m_rgb[1, torch.randperm(5120, generator=g)[:1520]] = True
+    m_dep = torch.ones(B, 5120, dtype=torch.bool)
+    done = torch.randperm(5120, generator=g)[:n_dec_so_far]
+    m_dep[:, done] = False                                              # depth tokens decoded by earlier steps
+    m_rgb, m_dep = m_rgb.to(DEV), m_dep.to(DEV)
+    enc_c = {"tok_rgb": (rgb, m_rgb), "tok_depth": (dep, m_dep)}
+    enc_u = {"tok_rgb": (rgb, torch.ones_like(m_rgb)), "tok_depth": (dep, m_dep)}
+    n_c, n_u = 4000 + n_dec_so_far, n_dec_so_far
+    open_pos = m_dep[0].nonzero()[:, 0]
+    pos = torch.stack([open_pos[torch.randperm(open_pos.numel(), generator=g)[:M].to(DEV)] for _ in range(B)])
+    sep_c = eng.infer_logits(enc_c, n_c, "tok_depth", pos).float().clone()
+    sep_u = eng.infer_logits(enc_u, n_u, "tok_depth", pos).float().clone()
+    pc, pu = eng.infer_logits_cfg(enc_c, n_c, enc_u, n_u, "tok_depth", pos)
+    pc, pu = pc.clone(), pu.clone()
+    for name, a, b in (("cond", pc.float(), sep_c), ("uncond", pu.float(), sep_u)):
+        assert torch.isfinite(a).all(), name
+        err = rel_l2(a.cpu().numpy(), b.cpu().numpy())
+        print("pair vs separate", name, "rel-l2", err)
+        assert err < 3e-3, (name, err)
+    assert rel_l2(pc.float().cpu().numpy(), pu.float().cpu().numpy()) > 1e-2         # the halves really saw different contexts
+    gc, gu = eng.infer_logits_cfg_graphed(enc_c, n_c, enc_u, n_u, "tok_depth", pos)
+    assert torch.equal(gc, pc) and torch.equal(gu, pu)
+    pos2 = torch.roll(pos, 5, dims=1)                                                  # replay on new positions
+    gc, gu = eng.infer_logits_cfg_graphed(enc_c, n_c, enc_u, n_u, "tok_depth", pos2)
+    pc2, pu2 = eng.infer_logits_cfg(enc_c, n_c, enc_u, n_u, "tok_depth", pos2)
+    assert torch.equal(gc, pc2) and torch.equal(gu, pu2)
+    # the knob: EGOM2P_CFG_PAIR=0 / eng.cfg_pair = False keeps the two-pass form in the sampler
+    eng.cfg_pair = False
+    sample = {"tok_rgb": {"tensor": rgb.view(B, 5, 32, 32)}}
+    sample = init_empty_target_modality(sample, MODALITY_INFO, "tok_depth", B, 5120, DEV)
+    sample = init_full_input_modality(sample, MODALITY_INFO, "tok_rgb", DEV)
+    sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
+                                             [2.0], ["constant"], cfg_grow_conditioning=True)
+    two = GenerationSampler(eng).generate(sample, sch, top_p=0.8, seed=5)["tok_depth"]["tensor"]
+    eng.cfg_pair = True
+    one = GenerationSampler(eng).generate(sample, sch, top_p=0.8, seed=5)["tok_depth"]["tensor"]
+    agree = (one == two).float().mean().item()
+    print("sampled tokens, paired vs two-pass decoder:", agree)
+    assert agree > 0.7          # random-init head: near-flat logits, bf16 noise flips near-ties (see the reference-pinned bars above)
+
+
 def test_padded_geometry_inference_pass_equals_the_training_path():
     """The registered ego-L geometry (dim 1020, 15 heads of 68: rows of 1024, heads of 128, ego_attn_*_hd kernels) on the
     generation path: one `infer_logits` pass (rgb inputs -> gaze targets) gives the logits of the training-path forward of

@@ -102,7 +102,7 @@ def test_registered_ego_l_geometry_through_the_module_surface():
                    mlp_ratio=4, qkv_bias=False, proj_bias=False, mlp_bias=False,
                    norm_layer=partial(LayerNorm, eps=1e-6, bias=False), act_layer=nn.SiLU, gated_mlp=True)
     eng = model.engine
-    assert eng.padded and (eng.D, eng.HDP) == (1024, 128)
+    assert eng.padded and (eng.D, eng.HDP, eng.Hs, eng.A) == (1024, 96, 16, 1536)      # 15 heads of 68 + one phantom head, zero
     assert sum(p.numel() for p in model.parameters()) == eng.num_params() == sum(v.numel() for k, v in sd.items()
                                                                                  if not k.endswith("pos_emb") and not (k.endswith(".bias") and "norm" in k)
                                                                                  and not (k.startswith("decoder_embeddings") and k.endswith(("mod_emb", "to_logits.weight"))))
