@@ -153,6 +153,12 @@ class GradBucketReducer:
                     t0.record(self.comm_stream)
                 self._exchange(lo, hi)
                 if t1 is not None:
+                    # torch's NCCL / RCCL group runs a collective on ITS OWN stream (ordered after the current one when it
+                    # is issued); Work.wait() orders the current stream - here the comm stream - after it again, without
+                    # blocking the host: only then does an event on the comm stream close the bucket's interval
+                    for w in self._works:
+                        w.wait()
+                    self._works.clear()
                     t1.record(self.comm_stream)
         else:
             import time
@@ -206,6 +212,8 @@ class GradBucketReducer:
             torch.cuda.synchronize(self.G.device)
             ex = sum(a.elapsed_time(b) for a, b, _ in buckets)
             exposed = wait[0].elapsed_time(wait[1]) if wait is not None else 0.0
+            if self.cabi is None and dist.get_backend(self.pg) == "gloo":
+                exposed = ex          # gloo on device tensors (one-GPU rehearsal): Work.wait() blocks the HOST - nothing overlaps
         else:
             ex = exposed = cpu * 1e3
         frac = 0.0 if ex <= 0 else max(0.0, min(1.0, 1.0 - exposed / ex))
