@@ -7,9 +7,9 @@
 // These are the PARITY kernels of a configuration nobody trains at scale (only the 400 M checkpoint is released): same
 // math and the same operand layouts as the d64 family - S^T = K Q'^T with the query on the lane, per-lane online softmax,
 // O^T = V^T P^T on key-permuted fragments (transposed operands by ds_read_b64_tr_b16 on the row-major tile) - but tiles are
-// staged through LDS by plain loads (the next tile's rows are fetched into registers while the current one is computed;
-// no LDS-DMA ring, no lazy softmax reference), and every key / query tile is visited.  The throughput shapes (head dim 64)
-// never come here.
+// staged through LDS by plain loads (two LDS stages, the tile after the next one in flight in registers; no LDS-DMA ring,
+// no lazy softmax reference); key / query tiles outside every row's interval are skipped.  The throughput shapes (head
+// dim 64) never come here.
 #include "common.h"
 #include "egom2p_hip.h"
 
@@ -113,24 +113,38 @@ __device__ __forceinline__ void store_rows(bf16_t* dst, bf16_t* lo, const f32x16
         }
 }
 
+// Key tiles [kt0, kt1) that at least one of the workgroup's 128 query rows attends: the union of the rows' intervals (an empty
+// interval has already become [0, Nk)).  A tile outside every row's interval contributes exact zeros (p = 0, alpha = 1), so
+// skipping it leaves the results bit for bit - the decoder's block-diagonal self-attention visits ~half of the tiles.
+__device__ __forceinline__ void key_tile_range(int ks, int ke, int nkt, int lane, int wave, int* w_lo, int* w_hi, int& kt0, int& kt1) {
+    const int lo = wave_min_i(ks), hi = wave_max_i(ke);
+    if (lane == 0) { w_lo[wave] = lo; w_hi[wave] = hi; }
+    __syncthreads();
+    kt0 = min(max(min(min(w_lo[0], w_lo[1]), min(w_lo[2], w_lo[3])), 0) >> 5, nkt);
+    kt1 = min((max(max(w_hi[0], w_hi[1]), max(w_hi[2], w_hi[3])) + 31) >> 5, nkt);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: workgroup = 128 queries of one (batch, head), wave = 32 of them (query on the lane)
 // ---------------------------------------------------------------------------------------------
-template <int HDP>
-__global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
+template <int HDP, int KS>
+__global__ __launch_bounds__(256, 2) void hd_fwd_kernel(HdArgs p) {
     typedef Tile<HDP> T;
-    constexpr int KS = HDP / 16, DB = HDP / 32;
-    __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Vn[T::NBYTES];
+    constexpr int DB = HDP / 32;        // KS: 16-wide contraction steps over the head dimension that hold non-zero columns
+    __shared__ __attribute__((aligned(16))) char Kn[2][T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Vn[2][T::NBYTES];
+    __shared__ int w_lo[4], w_hi[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles = (p.Nq + 127) >> 7;
-    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);      // every tile of a pair on one XCD (common.h)
     const int h = pair % p.H, b = pair / p.H;
     const int q0 = tile * 128 + wave * 32, ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
     int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
     float sc = p.scale * LOG2E;
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; }
+    int kt0, kt1;
+    key_tile_range(ks, ke, (p.Nk + 31) >> 5, lane, wave, w_lo, w_hi, kt0, kt1);
 
     const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * HDP;
     bf16x8 qf[KS];
@@ -149,26 +163,30 @@ __global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[db][i] = 0.f;
     float m = NEG_BIG, l = 0.f;
-    const int nkt = (p.Nk + 31) >> 5;
-    Pre<HDP> pk, pv;
-    fetch<HDP>(pk, Kb, p.k_rs, 0, p.Nk, tid);
-    fetch<HDP>(pv, Vb, p.v_rs, 0, p.Nk, tid);
-    for (int kt = 0; kt < nkt; ++kt) {
-        lds_barrier();                                              // the previous tile's readers are done
-        stash<HDP>(pk, Kn, tid);
-        stash<HDP>(pv, Vn, tid);
-        if (kt + 1 < nkt) {                                         // the next tile flies while this one is computed
-            fetch<HDP>(pk, Kb, p.k_rs, (kt + 1) * 32, p.Nk, tid);   // (lds_barrier orders LDS only: __syncthreads would wait
-            fetch<HDP>(pv, Vb, p.v_rs, (kt + 1) * 32, p.Nk, tid);   //  for these loads)
-        }
-        lds_barrier();
+    // two LDS stages: tile kt is computed from stage kt & 1 while tile kt + 1 (fetched into registers one iteration earlier)
+    // is written into the other stage and tile kt + 2 leaves global memory - one barrier per tile.  (Fetching two tiles ahead
+    // with a second register set was 14 % slower: the loop is bound by instruction issue, not by load latency.)
+    Pre<HDP> pkA, pvA;
+    fetch<HDP>(pkA, Kb, p.k_rs, kt0 * 32, p.Nk, tid);
+    fetch<HDP>(pvA, Vb, p.v_rs, kt0 * 32, p.Nk, tid);
+    stash<HDP>(pkA, Kn[0], tid);
+    stash<HDP>(pvA, Vn[0], tid);
+    if (kt0 + 1 < kt1) {
+        fetch<HDP>(pkA, Kb, p.k_rs, (kt0 + 1) * 32, p.Nk, tid);
+        fetch<HDP>(pvA, Vb, p.v_rs, (kt0 + 1) * 32, p.Nk, tid);
+    }
+    lds_barrier();
+    auto step = [&](int kt, Pre<HDP>& pk, Pre<HDP>& pv) {
+        const char* Kc = Kn[(kt - kt0) & 1];
+        const char* Vc = Vn[(kt - kt0) & 1];
         f32x16 st;
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kc, s, lane), qf[s], st, 0, 0, 0);
         float mx = NEG_BIG;
-        if (__all(kt * 32 >= ks && kt * 32 + 32 <= ke)) {           // the whole tile lies inside every row's interval
+        const bool inside = __all(kt * 32 >= ks && kt * 32 + 32 <= ke);      // the whole tile lies inside every row's interval
+        if (inside) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
         } else {
@@ -182,28 +200,49 @@ __global__ __launch_bounds__(256) void hd_fwd_kernel(HdArgs p) {
         }
         mx = xhalf_max(mx);
         const float mnew = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);       // (both NEG_BIG: 1, with l = 0 and O = 0)
-        l *= alpha;
+        if (__any(mnew != m)) {                                     // (alpha = 1 on every lane otherwise: the products are exact)
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // (both NEG_BIG: 1, with l = 0 and O = 0)
+            l *= alpha;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ot[db][i] *= alpha;
+                for (int i = 0; i < 16; ++i) ot[db][i] *= alpha;
+        }
         m = mnew;
         float rs = 0.f;
+        if (inside) {                                               // (every score is real: mnew is one of them)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pe = (st[r] <= NEG_BIG) ? 0.f : __builtin_amdgcn_exp2f(st[r] - mnew);
-            rs += pe;
-            st[r] = pe;
+            for (int r = 0; r < 16; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(st[r] - mnew);
+                rs += pe;
+                st[r] = pe;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pe = (st[r] <= NEG_BIG) ? 0.f : __builtin_amdgcn_exp2f(st[r] - mnew);
+                rs += pe;
+                st[r] = pe;
+            }
         }
         l += rs;
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const bf16x8 pf = pack8(st, x);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Vn, db, x, lane), pf, ot[db], 0, 0, 0);
+            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Vc, db, x, lane), pf, ot[db], 0, 0, 0);
         }
-    }
+        if (kt + 1 < kt1) {
+            stash<HDP>(pk, Kn[(kt - kt0 + 1) & 1], tid);            // tile kt + 1 (its stage's last readers passed the previous barrier)
+            stash<HDP>(pv, Vn[(kt - kt0 + 1) & 1], tid);
+            if (kt + 2 < kt1) {
+                fetch<HDP>(pk, Kb, p.k_rs, (kt + 2) * 32, p.Nk, tid);
+                fetch<HDP>(pv, Vb, p.v_rs, (kt + 2) * 32, p.Nk, tid);
+            }
+            lds_barrier();                                          // (orders LDS only: the fetches stay in flight)
+        }
+    };
+    for (int kt = kt0; kt < kt1; ++kt) step(kt, pkA, pvA);
     const float lt = xhalf_sum(l);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     if (q0 + ql < p.Nq) {
@@ -239,21 +278,24 @@ __global__ __launch_bounds__(256) void hd_delta_kernel(HdArgs p) {
 // ---------------------------------------------------------------------------------------------
 // backward, query-major: dQ = scale * sum_k dS K,  dS = P o (dP - delta)
 // ---------------------------------------------------------------------------------------------
-template <int HDP>
-__global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
+template <int HDP, int KS>
+__global__ __launch_bounds__(256, 2) void hd_dq_kernel(HdArgs p) {      // (3 waves per SIMD: 31 spilled registers, 60 % slower)
     typedef Tile<HDP> T;
-    constexpr int KS = HDP / 16, DB = HDP / 32;
-    __shared__ __attribute__((aligned(16))) char Kn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Vn[T::NBYTES];
+    constexpr int DB = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char Kn[2][T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Vn[2][T::NBYTES];
+    __shared__ int w_lo[4], w_hi[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles = (p.Nq + 127) >> 7;
-    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nq + 127) >> 7, p.r_rs == 0, pair, tile);      // every tile of a pair on one XCD (common.h)
     const int h = pair % p.H, b = pair / p.H;
     const int q0 = tile * 128 + wave * 32, ql = lane & 31, hh = lane >> 5;
     const int qrow = min(q0 + ql, p.Nq - 1);
     int ks = p.ks[b * p.r_bs + qrow * p.r_rs], ke = min(p.ke[b * p.r_bs + qrow * p.r_rs], p.Nk);
     float sc = p.scale * LOG2E, gsc = p.scale;
     if (ke <= ks) { ks = 0; ke = p.Nk; sc = 0.f; gsc = 0.f; }
+    int kt0, kt1;
+    key_tile_range(ks, ke, (p.Nk + 31) >> 5, lane, wave, w_lo, w_hi, kt0, kt1);
     const long li = ((long)b * p.H + h) * p.Nq + qrow;
     const float lse2 = p.LSE[li], delta = p.DELTA[li];
 
@@ -275,26 +317,26 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqt[db][i] = 0.f;
-    const int nkt = (p.Nk + 31) >> 5;
-    Pre<HDP> pk, pv;
-    fetch<HDP>(pk, Kb, p.k_rs, 0, p.Nk, tid);
-    fetch<HDP>(pv, Vb, p.v_rs, 0, p.Nk, tid);
-    for (int kt = 0; kt < nkt; ++kt) {
-        lds_barrier();
-        stash<HDP>(pk, Kn, tid);
-        stash<HDP>(pv, Vn, tid);
-        if (kt + 1 < nkt) {
-            fetch<HDP>(pk, Kb, p.k_rs, (kt + 1) * 32, p.Nk, tid);
-            fetch<HDP>(pv, Vb, p.v_rs, (kt + 1) * 32, p.Nk, tid);
-        }
-        lds_barrier();
+    Pre<HDP> pk, pv;                                                // two LDS stages, one barrier per tile (hd_fwd_kernel)
+    fetch<HDP>(pk, Kb, p.k_rs, kt0 * 32, p.Nk, tid);
+    fetch<HDP>(pv, Vb, p.v_rs, kt0 * 32, p.Nk, tid);
+    stash<HDP>(pk, Kn[0], tid);
+    stash<HDP>(pv, Vn[0], tid);
+    if (kt0 + 1 < kt1) {
+        fetch<HDP>(pk, Kb, p.k_rs, (kt0 + 1) * 32, p.Nk, tid);
+        fetch<HDP>(pv, Vb, p.v_rs, (kt0 + 1) * 32, p.Nk, tid);
+    }
+    lds_barrier();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const char* Kc = Kn[(kt - kt0) & 1];
+        const char* Vc = Vn[(kt - kt0) & 1];
         f32x16 st, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kn, s, lane), qf[s], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Vn, s, lane), gf[s], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Kc, s, lane), qf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Vc, s, lane), gf[s], dp, 0, 0, 0);
         }
         if (__all(kt * 32 >= ks && kt * 32 + 32 <= ke)) {
 #pragma unroll
@@ -311,7 +353,16 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
         for (int x = 0; x < 2; ++x) {
             const bf16x8 df = pack8(st, x);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Kn, db, x, lane), df, dqt[db], 0, 0, 0);
+            for (int db = 0; db < DB; ++db) dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Kc, db, x, lane), df, dqt[db], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) {
+            stash<HDP>(pk, Kn[(kt - kt0 + 1) & 1], tid);
+            stash<HDP>(pv, Vn[(kt - kt0 + 1) & 1], tid);
+            if (kt + 2 < kt1) {
+                fetch<HDP>(pk, Kb, p.k_rs, (kt + 2) * 32, p.Nk, tid);
+                fetch<HDP>(pv, Vb, p.v_rs, (kt + 2) * 32, p.Nk, tid);
+            }
+            lds_barrier();
         }
     }
     if (q0 + ql < p.Nq)
@@ -321,22 +372,41 @@ __global__ __launch_bounds__(256) void hd_dq_kernel(HdArgs p) {
 // ---------------------------------------------------------------------------------------------
 // backward, key-major: dV = P^T dO,  dK = scale * dS^T Q (workgroup = 128 keys, wave = 32 of them, key on the lane)
 // ---------------------------------------------------------------------------------------------
-template <int HDP>
-__global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
+template <int HDP, int KS>
+__global__ __launch_bounds__(256, HDP <= 96 ? 2 : 1) void hd_dkv_kernel(HdArgs p) {     // (heads of 128: 2 waves per SIMD would spill 93 registers)
     typedef Tile<HDP> T;
-    constexpr int KS = HDP / 16, DB = HDP / 32;
-    __shared__ __attribute__((aligned(16))) char Qn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) char Gn[T::NBYTES];
-    __shared__ __attribute__((aligned(16))) float a_lse[32], a_delta[32];
-    __shared__ __attribute__((aligned(16))) int a_ks[32], a_ke[32];
+    constexpr int DB = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char Qn[2][T::NBYTES];
+    __shared__ __attribute__((aligned(16))) char Gn[2][T::NBYTES];
+    __shared__ __attribute__((aligned(16))) float a_lse[2][32], a_delta[2][32];
+    __shared__ __attribute__((aligned(16))) int a_ks[2][32], a_ke[2][32];
+    __shared__ int w_lo[4], w_hi[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles = (p.Nk + 127) >> 7;
-    const int pair = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    int pair, tile;
+    pair_tile(blockIdx.x, p.B * p.H, (p.Nk + 127) >> 7, p.r_rs == 0, pair, tile);
     const int h = pair % p.H, b = pair / p.H;
     const int kl = lane & 31, hh = lane >> 5;
     const int kidx = tile * 128 + wave * 32 + kl;
     const int krow = min(kidx, p.Nk - 1);
     const float c_sc = p.scale * LOG2E;
+    // Query tiles [qt0, qt1) with at least one row that attends a key of this workgroup (an empty interval attends every key):
+    // every other tile contributes exact zeros.  One pass over the rows' intervals (Nq / 256 loads per thread).
+    int qt0, qt1;
+    {
+        const int k0 = tile * 128, k1 = min(k0 + 128, p.Nk);
+        int qlo = 0x7fffffff, qhi = -1;
+        for (int q = tid; q < p.Nq; q += 256) {
+            const int a = p.ks[b * p.r_bs + q * p.r_rs], e = min(p.ke[b * p.r_bs + q * p.r_rs], p.Nk);
+            if (e <= a || (a < k1 && e > k0)) { qlo = min(qlo, q); qhi = max(qhi, q); }
+        }
+        qlo = wave_min_i(qlo); qhi = wave_max_i(qhi);
+        if (lane == 0) { w_lo[wave] = qlo; w_hi[wave] = qhi; }
+        __syncthreads();
+        qlo = min(min(w_lo[0], w_lo[1]), min(w_lo[2], w_lo[3]));
+        qhi = max(max(w_hi[0], w_hi[1]), max(w_hi[2], w_hi[3]));
+        qt0 = qhi < 0 ? 0 : qlo >> 5;
+        qt1 = qhi < 0 ? 0 : (qhi >> 5) + 1;
+    }
     const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)krow * p.k_rs + h * HDP;
     const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)krow * p.v_rs + h * HDP;
     bf16x8 kf[KS], vf[KS];
@@ -356,7 +426,6 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkt[db][i] = 0.f; dvt[db][i] = 0.f; }
-    const int nqt = (p.Nq + 31) >> 5;
     // the next query tile on its way: rows of Q and dO, and (threads 0-31) the tile's row constants
     Pre<HDP> pq, pg;
     float n_lse = 0.f, n_delta = 0.f;
@@ -374,33 +443,40 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
             if (q >= p.Nq) { n_ks = 0x7fffffff; n_ke = -1; }             // a row past Nq sees no key (and is not "flat")
         }
     };
-    fetch_tile(0);
-    for (int qt = 0; qt < nqt; ++qt) {
+    auto stash_tile = [&](int st) {
+        stash<HDP>(pq, Qn[st], tid);
+        stash<HDP>(pg, Gn[st], tid);
+        if (tid < 32) { a_lse[st][tid] = n_lse; a_delta[st][tid] = n_delta; a_ks[st][tid] = n_ks; a_ke[st][tid] = n_ke; }
+    };
+    if (qt0 < qt1) {                                                    // two LDS stages, one barrier per tile (hd_fwd_kernel)
+        fetch_tile(qt0);
+        stash_tile(0);
+        if (qt0 + 1 < qt1) fetch_tile(qt0 + 1);
         lds_barrier();
-        stash<HDP>(pq, Qn, tid);
-        stash<HDP>(pg, Gn, tid);
-        if (tid < 32) { a_lse[tid] = n_lse; a_delta[tid] = n_delta; a_ks[tid] = n_ks; a_ke[tid] = n_ke; }
-        if (qt + 1 < nqt) fetch_tile(qt + 1);
-        lds_barrier();
+    }
+    for (int qt = qt0; qt < qt1; ++qt) {
+        const int cur = (qt - qt0) & 1;
+        const char* Qc = Qn[cur];
+        const char* Gc = Gn[cur];
         f32x16 st, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Qn, s, lane), kf[s], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Gn, s, lane), vf[s], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Qc, s, lane), kf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nat_frag<HDP>(Gc, s, lane), vf[s], dp, 0, 0, 0);
         }
         // row constants of this lane's 16 query rows: acc_row(4g + e, hh) = 8g + 4hh + e, four consecutive rows per g
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         const int kw0 = tile * 128 + wave * 32;
         bool full;
         {   // every row of the tile sees all 32 keys of this wave (no empty interval, no row past Nq, no key past Nk)?
-            const int rks = a_ks[kl], rke = a_ke[kl];
+            const int rks = a_ks[cur][kl], rke = a_ke[cur][kl];
             full = __all(rke > rks && rks <= kw0 && rke >= kw0 + 32) && kw0 + 32 <= p.Nk;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 L = *(const f32x4*)&a_lse[8 * g + 4 * hh], Dl = *(const f32x4*)&a_delta[8 * g + 4 * hh];
+            const f32x4 L = *(const f32x4*)&a_lse[cur][8 * g + 4 * hh], Dl = *(const f32x4*)&a_delta[cur][8 * g + 4 * hh];
             if (full) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -410,7 +486,7 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
                     dp[r] = pe * (dp[r] - Dl[e]);
                 }
             } else {
-                const i32x4 KS4 = *(const i32x4*)&a_ks[8 * g + 4 * hh], KE4 = *(const i32x4*)&a_ke[8 * g + 4 * hh];
+                const i32x4 KS4 = *(const i32x4*)&a_ks[cur][8 * g + 4 * hh], KE4 = *(const i32x4*)&a_ke[cur][8 * g + 4 * hh];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
@@ -430,9 +506,14 @@ __global__ __launch_bounds__(256) void hd_dkv_kernel(HdArgs p) {
             const bf16x8 pf = pack8(st, x), df = pack8(dp, x);
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Gn, db, x, lane), pf, dvt[db], 0, 0, 0);
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Qn, db, x, lane), df, dkt[db], 0, 0, 0);
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Gc, db, x, lane), pf, dvt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trn_frag<HDP>(Qc, db, x, lane), df, dkt[db], 0, 0, 0);
             }
+        }
+        if (qt + 1 < qt1) {
+            stash_tile(cur ^ 1);
+            if (qt + 2 < qt1) fetch_tile(qt + 2);
+            lds_barrier();
         }
     }
     if (kidx < p.Nk) {
@@ -446,7 +527,26 @@ bool check(const HdArgs& a, int hdp) {
            a.v_rs % 8 == 0 && a.q_bs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0 && a.o_rs % 8 == 0 && a.o_bs % 8 == 0;
 }
 
+// hd_pad argument of the entry points: low 16 bits = elements between two stored heads (96 / 128); bits 16.. (optional, 0 =
+// not given) = the head's real dimension: contraction steps over columns that are all padding (exact zeros) are left out -
+// the registered ego-L's 68 of 96 need 5 of the 6 steps.  Same bits either way.
+struct HdShape { int hdp, ks; };
+HdShape hd_shape(int hd_pad) {
+    const int hdp = hd_pad & 0xffff, hd = hd_pad >> 16;
+    int ks = hdp / 16;
+    if (hd > 0 && hd <= hdp && (hd + 15) / 16 <= 5) ks = 5;          // instantiated: all steps, or 5 (head dims 65 .. 80)
+    return {hdp, ks};
+}
+
 }  // namespace
+
+#define HD_DISPATCH(KERNEL, grid)                                                                      \
+    do {                                                                                               \
+        if (sh.hdp == 96 && sh.ks == 5) { EGO_LAUNCH((KERNEL<96, 5>), grid, dim3(256), 0, stream, a); } \
+        else if (sh.hdp == 96) { EGO_LAUNCH((KERNEL<96, 6>), grid, dim3(256), 0, stream, a); }          \
+        else if (sh.ks == 5) { EGO_LAUNCH((KERNEL<128, 5>), grid, dim3(256), 0, stream, a); }           \
+        else { EGO_LAUNCH((KERNEL<128, 8>), grid, dim3(256), 0, stream, a); }                           \
+    } while (0)
 
 extern "C" int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V,
                                long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks,
@@ -458,11 +558,11 @@ extern "C" int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* 
     a.O = (bf16_t*)O; a.o_bs = o_bs; a.o_rs = o_rs; a.Olo = (bf16_t*)O_lo; a.LSE = LSE; a.ks = ks; a.ke = ke; a.r_bs = r_bs; a.r_rs = r_rs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (B == 0 || Nq == 0) return EGO_OK;
+    const HdShape sh = hd_shape(hd_pad);
     // 16-byte row fragments in and out, like ego_attn_fwd_d64
-    if (!check(a, hd_pad) || ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O) | ((uintptr_t)O_lo)) & 15)) return EGO_ERR_ARG;
+    if (!check(a, sh.hdp) || ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O) | ((uintptr_t)O_lo)) & 15)) return EGO_ERR_ARG;
     const dim3 grid(B * H * ((Nq + 127) / 128));
-    if (hd_pad == 96) { EGO_LAUNCH(hd_fwd_kernel<96>, grid, dim3(256), 0, stream, a); }
-    else { EGO_LAUNCH(hd_fwd_kernel<128>, grid, dim3(256), 0, stream, a); }
+    HD_DISPATCH(hd_fwd_kernel, grid);
     LAUNCH_CHECK();
     return EGO_OK;
 }
@@ -484,20 +584,16 @@ extern "C" int ego_attn_bwd_hd(const void* Q, long q_bs, long q_rs, const void* 
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
     if (B == 0 || Nq == 0) return EGO_OK;
-    if (!check(a, hd_pad) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 ||
+    const HdShape sh = hd_shape(hd_pad);
+    if (!check(a, sh.hdp) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 ||
         ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O) | ((uintptr_t)O_lo) | ((uintptr_t)dO) | ((uintptr_t)dQ) |
           ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;      // 16-byte row fragments, gradient rows included
     const long rows = (long)B * H * Nq;
     const dim3 gq(B * H * ((Nq + 127) / 128)), gk(B * H * ((Nk + 127) / 128)), gd((unsigned)((rows + 255) / 256));
-    if (hd_pad == 96) {
-        EGO_LAUNCH(hd_delta_kernel<96>, gd, dim3(256), 0, stream, a);
-        EGO_LAUNCH(hd_dq_kernel<96>, gq, dim3(256), 0, stream, a);
-        EGO_LAUNCH(hd_dkv_kernel<96>, gk, dim3(256), 0, stream, a);
-    } else {
-        EGO_LAUNCH(hd_delta_kernel<128>, gd, dim3(256), 0, stream, a);
-        EGO_LAUNCH(hd_dq_kernel<128>, gq, dim3(256), 0, stream, a);
-        EGO_LAUNCH(hd_dkv_kernel<128>, gk, dim3(256), 0, stream, a);
-    }
+    if (sh.hdp == 96) { EGO_LAUNCH(hd_delta_kernel<96>, gd, dim3(256), 0, stream, a); }
+    else { EGO_LAUNCH(hd_delta_kernel<128>, gd, dim3(256), 0, stream, a); }
+    HD_DISPATCH(hd_dq_kernel, gq);
+    HD_DISPATCH(hd_dkv_kernel, gk);
     LAUNCH_CHECK();
     return EGO_OK;
 }

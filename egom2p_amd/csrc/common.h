@@ -144,6 +144,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Attention kernels (attention.hip, attention_hd.hip): workgroup id -> ((batch, head) pair, tile).  The hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs and the resident workgroups are a contiguous id range.  B * H is a multiple of 8 for the model's shapes, so
+// both orders below keep every tile of one pair on ONE XCD (with the tile index fastest over the whole grid all 8
+// L2s re-fetched each K / V stream: 2x slower on the block-diagonal decoder mask).
+//   * walk = true (one interval per batch row: encoder self-attention, cross-attention - every tile costs the
+//     same): consecutive ids of an XCD walk the tiles of ONE pair, so only 96 / tiles pairs are alive per L2 and
+//     their K / V (Q / dO) streams stay in its 4 MB.  rocprofv3 FETCH_SIZE at B 32: 2.55 GB -> 0.35 GB per forward
+//     launch, 6-7 % less time (the streams came from HBM: qkv of one micro-batch is 300 MB, beyond the 256 MB MALL).
+//   * walk = false (per-row intervals, block-diagonal decoder mask: tile costs differ up to 2x): pair index
+//     fastest; the tile walk ran 5-25 % slower there.
+__device__ __forceinline__ void pair_tile(int id, int pairs, int tiles, bool walk, int& pair, int& tile) {
+    if (walk && (pairs & 7) == 0) {
+        const int x = id & 7, j = id >> 3;
+        pair = (j / tiles) * 8 + x;
+        tile = j % tiles;
+    } else {
+        pair = id % pairs;
+        tile = id / pairs;
+    }
+}
+
 // Ordered column sums of per-workgroup partial rows (rowops.hip): dst.p[c / seg][c % seg] += sum_r parts[r][c], rows summed
 // in index order, so gradients reduced this way are bitwise reproducible (no float atomics).  `parts` must have room for
 // colsum_work_floats(n, W) floats (the partial rows followed by the intermediate levels).

@@ -582,7 +582,7 @@ class Engine:
         ops.attn_fwd(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, lse, ks, ke, r_bs, r_rs,
                      B, self.Hs, Nq, Nk, self.scale, o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP,
-                     seg=seg, seg_bad=seg_bad)
+                     seg=seg, seg_bad=seg_bad, hd=self.HD)
 
     # generation path: under-filled attention grids (1707 decoder rows x 12 heads = 168 workgroups on 256 CUs, each walking every
     # key tile serially: 26 - 47 us per launch) get their keys cut into runs (ego_attn_fwd_d64_split) until ~640 workgroups exist
@@ -622,7 +622,7 @@ class Engine:
                      kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, do_t.data_ptr(), Nq * A, A,
                      lse, self.delta, dq_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, dkv_t.data_ptr() + 2 * k_off, Nk * kv_rs,
                      kv_rs, dkv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, ks, ke, r_bs, r_rs, B, self.Hs, Nq, Nk, self.scale,
-                     o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP, seg=seg, seg_bad=seg_bad)
+                     o_lo=None if o_lo is None else o_lo.data_ptr(), hd_pad=self.HDP, seg=seg, seg_bad=seg_bad, hd=self.HD)
 
     # ------------------------------------------------------------------------------------ forward
     def forward(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], dec_order: Optional[Sequence[str]] = None,

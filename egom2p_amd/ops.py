@@ -172,10 +172,16 @@ def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
     return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))
 
 
+def _hd_arg(hd_pad, hd):
+    """`hd_pad` argument of the ego_attn_*_hd entries: pitch of a stored head, plus (optional) the head's real dimension in bits 16.."""
+    return int(hd_pad) | ((int(hd) << 16) if hd else 0)
+
+
 def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None,
-             hd_pad=64, seg=None, seg_bad=None):
+             hd_pad=64, seg=None, seg_bad=None, hd=None):
     """o_lo (optional device pointer, laid out like o): receives the bf16 rounding residual of the output.
-    hd_pad: elements per stored head (64: the throughput kernels; 96 / 128: zero-padded heads of another dimension)
+    hd_pad: elements per stored head (64: the throughput kernels; 96 / 128: zero-padded heads of another dimension; hd: that
+    dimension, optional - contraction steps over all-padding columns are then skipped)
     seg (int32 [B, n_seg, 2], optional; head_dim 64 only): row groups of a block-diagonal self-attention mask, seg_bad (int32 [B],
     optional): samples that must take the per-row intervals instead (ego_attn_fwd_d64_seg)"""
     if hd_pad == 64 and seg is not None:
@@ -185,7 +191,7 @@ def attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks
         return
     if hd_pad != 64:
         check(L.load().ego_attn_fwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
-                                       r_bs, r_rs, B, H, Nq, Nk, hd_pad, scale, _stream()), "ego_attn_fwd_hd")
+                                       r_bs, r_rs, B, H, Nq, Nk, _hd_arg(hd_pad, hd), scale, _stream()), "ego_attn_fwd_hd")
         return
     check(L.load().ego_attn_fwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, _p(lse), _p(ks), _p(ke),
                                     r_bs, r_rs, B, H, Nq, Nk, scale, _stream()), "ego_attn_fwd_d64")
@@ -205,7 +211,7 @@ def attn_fwd_split_floats(B, H, Nq, kv_splits):
 
 def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_bs, do_rs, lse, delta,
              dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, ks, ke, r_bs, r_rs, B, H, Nq, Nk, scale, o_lo=None, hd_pad=64,
-             seg=None, seg_bad=None):
+             seg=None, seg_bad=None, hd=None):
     if hd_pad == 64 and seg is not None:
         check(L.load().ego_attn_bwd_d64_seg(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                             _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
@@ -215,7 +221,7 @@ def attn_bwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, do, do_
     if hd_pad != 64:
         check(L.load().ego_attn_bwd_hd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                        _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,
-                                       _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, hd_pad, scale, _stream()), "ego_attn_bwd_hd")
+                                       _p(ks), _p(ke), r_bs, r_rs, B, H, Nq, Nk, _hd_arg(hd_pad, hd), scale, _stream()), "ego_attn_bwd_hd")
         return
     check(L.load().ego_attn_bwd_d64(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, o_lo, do, do_bs, do_rs,
                                     _p(lse), _p(delta), dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs,

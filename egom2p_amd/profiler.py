@@ -86,11 +86,11 @@ class KernelTimer:
             return n
 
         def c_attn_fwd(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, lse, ks, ke, r_bs, r_rs, B, Hh, Nq, Nk, scale, o_lo=None,
-                       hd_pad=64, seg=None, seg_bad=None):
+                       hd_pad=64, seg=None, seg_bad=None, hd=None):
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
             return 4.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((3 if o_lo is not None else 2) * Nq + 2 * Nk)
 
-        def c_attn_bwd(*a, o_lo=None, hd_pad=64, seg=None, seg_bad=None):
+        def c_attn_bwd(*a, o_lo=None, hd_pad=64, seg=None, seg_bad=None, hd=None):
             ks, ke, r_bs, r_rs, B, Hh, Nq, Nk = a[-9], a[-8], a[-7], a[-6], a[-5], a[-4], a[-3], a[-2]
             p = _pairs(ks, ke, r_bs, r_rs, B, Nq, Nk)
             return 10.0 * hd_pad * Hh * p, 2.0 * B * Hh * hd_pad * ((5 if o_lo is not None else 4) * Nq + 4 * Nk)

@@ -220,8 +220,11 @@ int ego_attn_bwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, lon
 
 /* The same two entries for a head dimension other than 64: every head is stored padded with zero columns to
  * hd_pad = 96 or 128 elements (the registered ego-L, egom2p_model.py:1080-1092, has 15 heads of 68: 68^-0.5 is `scale`),
- * head h of a row at element offset h * hd_pad.  Parity kernels (LDS-staged tiles, every tile visited), not the
- * throughput path.  LSE / DELTA are opaque to the caller, as above; other hd_pad -> EGO_ERR_ARG. */
+ * head h of a row at element offset h * hd_pad.  LDS-staged 32-row tiles (tiles outside every row's interval are skipped);
+ * not the throughput path of the head-dim-64 models.  hd_pad: the low 16 bits are that pitch; bits 16 and up may carry the
+ * head's real dimension (68: hd_pad = 96 | 68 << 16; 0 = not given) - contraction steps over columns that are all padding
+ * are then left out, the results are the same bits.  LSE / DELTA are opaque to the caller, as above; other pitches ->
+ * EGO_ERR_ARG. */
 int ego_attn_fwd_hd(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs, const void* V, long v_bs,
                     long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE, const int* ks, const int* ke,
                     long r_bs, long r_rs, int B, int H, int Nq, int Nk, int hd_pad, float scale, hipStream_t stream);

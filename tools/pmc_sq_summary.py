@@ -18,7 +18,8 @@ from egom2p_amd.profiler import kernel_source_sha  # noqa: E402
 
 CLASSES = [("gemm_nt256<0>", r"gemm_nt256_kernel<0"), ("gemm_nt256<1>", r"gemm_nt256_kernel<1"), ("gemm_nt256<2>", r"gemm_nt256_kernel<2"),
            ("gemm_nt256<3>", r"gemm_nt256_kernel<3"), ("gemm_tn256", r"gemm_tn256_kernel"), ("attn_fwd", r"attn_fwd_kernel"),
-           ("attn_bwd_dq", r"attn_bwd_dq_kernel"), ("attn_bwd_dkv", r"attn_bwd_dkv_kernel")]
+           ("attn_bwd_dq", r"attn_bwd_dq_kernel"), ("attn_bwd_dkv", r"attn_bwd_dkv_kernel"),
+           ("hd_fwd", r"hd_fwd_kernel"), ("hd_dq", r"hd_dq_kernel"), ("hd_dkv", r"hd_dkv_kernel")]
 
 
 def main():
