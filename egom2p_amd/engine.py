@@ -943,7 +943,7 @@ class Engine:
         if not fresh and self._infer_key is not None and self._infer_key[0] >= G and all(a >= b for a, b in zip(self._infer_key[1:], key[1:])):
             return self._iw
         D, A, Fp, H, dev = self.D, self.A, self.Fp, self.Hs, self.dev
-        RE, RD, RC = B * Nmax, G * B * Mmax, G * B * Nmax         # encoder rows of one pass, decoder rows, context rows
+        RE, RD, RC = G * B * Nmax, G * B * Mmax, G * B * Nmax     # encoder rows (all groups, back to back), decoder rows, context rows
         R = max(RE, RD)
 
         def e(*shape, dt=BF16):
@@ -973,30 +973,37 @@ class Engine:
             self._iw, self._infer_key = w, key
         return w
 
-    def _infer_context(self, w, side, enc_inputs, N: int, B: int, ctx: torch.Tensor):
+    def _infer_context(self, w, parts, B: int):
         """Encoder half of a generation pass: compaction of the unmasked inputs, embeddings, encoder blocks,
-        decoder_proj_context (+ embeddings) -> ctx [B * N, D] fp32 (forward_mask_encoder_generation + encoder,
-        egom2p/models/generate.py:747-757)."""
+        decoder_proj_context (+ embeddings) -> w["ctx"] fp32 (forward_mask_encoder_generation + encoder,
+        egom2p/models/generate.py:747-757).  parts = [(side, enc_inputs, N, first row)]: one entry per group of B samples
+        (the conditional and the unconditional inputs of a guided step); the groups' rows lie back to back, every row-wise
+        launch (LayerNorm, GEMMs, gate) covers all of them - the unconditional pass's 1707 / 3414 rows alone leave most CUs
+        idle - compaction, embedding and self-attention run per group (own row counts)."""
         cfg, D, A = self.cfg, self.D, self.A
-        mods = [m for m in self.mods if m.name in enc_inputs]
-        RN = B * N
-        ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
-                    None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
+        parts = [p for p in parts if p[2] > 0]
+        R = sum(B * n for _, _, n, _ in parts)
         x, xn = w["xa"], w["xb"]
-        ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
-                      [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
-                      x, w["emb"], RN, D)
+        for side, enc_inputs, N, r0 in parts:
+            mods = [m for m in self.mods if m.name in enc_inputs]
+            ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
+                        None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
+            ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
+                          [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
+                          x[r0:], w["emb"][r0:], B * N, D)
         for i in range(cfg.encoder_depth):
             pre = f"encoder.{i}"
-            self._ln(x[:RN], f"{pre}.norm1.weight", w["ln"], w["st"])
-            self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], RN)
-            self._attn_infer(w, w["qkv"], 0, 3 * A, w["qkv"], A, 2 * A, 3 * A, w["ao"], w["zero_b"], side["n_valid"], B, N, N)
-            self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, RN, L.EPI_RESID, R=x)
-            self._ln(xn[:RN], f"{pre}.norm2.weight", w["ln"], w["st"])
-            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RN)
-            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, RN, L.EPI_RESID, R=xn)
-        self._ln(x[:RN], "encoder_norm.weight", w["ln"], w["st"])
-        self._lin_fwd("decoder_proj_context.weight", w["ln"], ctx, RN, L.EPI_BIAS_RESID, R=w["emb"],
+            self._ln(x[:R], f"{pre}.norm1.weight", w["ln"], w["st"])
+            self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], R)
+            for side, _, N, r0 in parts:
+                self._attn_infer(w, w["qkv"], r0 * 3 * A, 3 * A, w["qkv"], r0 * 3 * A + A, r0 * 3 * A + 2 * A, 3 * A, w["ao"][r0:], w["zero_b"],
+                                 side["n_valid"], B, N, N)
+            self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, R, L.EPI_RESID, R=x)
+            self._ln(xn[:R], f"{pre}.norm2.weight", w["ln"], w["st"])
+            self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], R)
+            self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], x, R, L.EPI_RESID, R=xn)
+        self._ln(x[:R], "encoder_norm.weight", w["ln"], w["st"])
+        self._lin_fwd("decoder_proj_context.weight", w["ln"], w["ctx"], R, L.EPI_BIAS_RESID, R=w["emb"],
                       bias=self.p["decoder_proj_context.bias"])
 
     def _infer_decode(self, w, parts, target: str, dec_pos: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
@@ -1073,7 +1080,7 @@ class Engine:
         w = ws if ws is not None else self._alloc_infer(B, max(N, 1), M)
         side = w["sides"][0]
         if N > 0:
-            self._infer_context(w, side, enc_inputs, N, B, w["ctx"])
+            self._infer_context(w, [(side, enc_inputs, N, 0)], B)
         logits = self._infer_decode(w, [(side, N, 0)], target, dec_pos, out)
         return logits.view(B, M, -1)
 
@@ -1081,10 +1088,11 @@ class Engine:
     def infer_logits_cfg(self, enc_cond, n_cond: int, enc_uncond, n_uncond: int, target: str, dec_pos: torch.Tensor,
                          out: Optional[torch.Tensor] = None, ws: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """The conditional and the unconditional pass of one classifier-free-guidance step (generate.py:881-905 runs
-        forward_enc_dec_roar_batched twice) with ONE decoder pass: both decode the same positions from the same mask-token
-        rows, only the cross-attention context differs.  Two encoder passes fill one context buffer back to back; the
-        decoder runs 2 B samples per launch (the launches of this path are latency-bound: twice the rows cost the same
-        time) and cross-attends per half.  Returns (logits_cond, logits_uncond), each bf16 [B, M, V]."""
+        forward_enc_dec_roar_batched twice) as ONE pass: the encoder runs the two input sets as two groups of rows back to
+        back (row-wise launches cover both, self-attention per group); both passes decode the same positions from the same
+        mask-token rows, only the cross-attention context differs - the decoder runs 2 B samples per launch (the launches
+        of this path are latency-bound: twice the rows cost the same time) and cross-attends per half.
+        Returns (logits_cond, logits_uncond), each bf16 [B, M, V]."""
         if self.weights_dirty:
             self.refresh_weights()
         B, M = dec_pos.shape
@@ -1095,9 +1103,7 @@ class Engine:
         if w["groups"] < 2:
             raise ValueError("workspace allocated for single passes (groups=1)")
         sc, su = w["sides"]
-        self._infer_context(w, sc, enc_cond, Nc, B, w["ctx"])
-        if Nu > 0:
-            self._infer_context(w, su, enc_uncond, Nu, B, w["ctx"][B * Nc:])
+        self._infer_context(w, [(sc, enc_cond, Nc, 0), (su, enc_uncond, Nu, B * Nc)], B)
         logits = self._infer_decode(w, [(sc, Nc, 0), (su, Nu, B * Nc)], target, dec_pos, out)
         V = logits.shape[-1]
         return logits[:B * M].view(B, M, V), logits[B * M:2 * B * M].view(B, M, V)
