@@ -384,9 +384,11 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         # live HIP-event timing of one micro-batch forward+backward, per kernel class
         kt = KernelTimer()
+        pair, eng.pair_stream = eng.pair_stream, None      # per-kernel times: every launch alone (the timed steps above pair wgrad GEMMs with LayerNorm backward launches)
         with kt.capture(cfg.num_heads):
             eng.forward(mbs[0], dec_order=[m.name for m in cfg.mods], loss_grad=1.0)
             eng.backward(1.0)
+        eng.pair_stream = pair
         eng.zero_grad()
         summ = kt.summary()
         mfma = {k: v for k, v in summ.items() if v["flops"] > 0}

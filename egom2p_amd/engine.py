@@ -33,6 +33,9 @@ F32 = torch.float32
 I32 = torch.int32
 
 
+_PAIR_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
 def _pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 
@@ -115,6 +118,18 @@ class Engine:
         # at every bucket boundary.  Measured on MI355X: parity-clean but 5 % SLOWER than one stream (the co-running
         # kernels fight for LDS / L2), so it is off by default (EGOM2P_WGRAD_STREAM=1 enables it).
         self.side = torch.cuda.Stream(device=self.dev) if os.environ.get("EGOM2P_WGRAD_STREAM", "0") == "1" else None
+        # optional (EGOM2P_WGRAD_PAIR=1): weight-gradient GEMMs paired with the LayerNorm backward launches (MFMA-bound beside
+        # HBM-bound, never two MFMA kernels at once): _ln_bwd.  Measured on MI355X: 191.1 vs 190.5 clips/s (two runs each, one
+        # box) - inside the noise: the LayerNorm backward already takes 5.4 TB/s and the GEMM's own 2.4 TB/s has nowhere to go.  Off.
+        self._pend, self.pair_stream = None, None
+        if self.side is None and os.environ.get("EGOM2P_WGRAD_PAIR", "0") == "1":
+            # ONE second stream per device and process (every torch.cuda.Stream() is another hardware queue; a long-lived process
+            # that builds many engines - the test suite - would otherwise oversubscribe the queues of a GPU it shares)
+            key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+            if key not in _PAIR_STREAMS:
+                _PAIR_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+            self.pair_stream = _PAIR_STREAMS[key]
+            self._pair_ev, self._pair_i = [torch.cuda.Event() for _ in range(16)], 0
         # decoder self-attention launched by row groups (one interval per workgroup); 0: per-row interval launches (round 3)
         self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
         self.attn_split = os.environ.get("EGOM2P_ATTN_SPLIT", "1") != "0"       # generation path: split keys on under-filled grids
@@ -129,8 +144,30 @@ class Engine:
         return self.ring_b[self._ring_i]
 
     def _join_side(self):
+        if self._pend is not None:                 # paired mode: a weight gradient still held back goes out now
+            self._pend()
+            self._pend = None
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+
+    def _ln_bwd(self, *a, **kw):
+        """ops.layernorm_bwd - an HBM-bound launch that leaves the MFMA pipes idle - with the weight-gradient GEMM that was held
+        back (an MFMA-bound launch with no consumer before the next bucket boundary) beside it on a second stream: the GEMM
+        starts when the LayerNorm does, and the main stream goes on only after both (two MFMA kernels never overlap: that was
+        measured 5 - 26 % slower)."""
+        run, self._pend = self._pend, None
+        if run is None:
+            return ops.layernorm_bwd(*a, **kw)
+        main = torch.cuda.current_stream()
+        e0, e1 = self._pair_ev[self._pair_i], self._pair_ev[self._pair_i + 1]
+        self._pair_i = (self._pair_i + 2) % len(self._pair_ev)
+        e0.record(main)
+        with torch.cuda.stream(self.pair_stream):
+            self.pair_stream.wait_event(e0)
+            run()
+            e1.record(self.pair_stream)
+        ops.layernorm_bwd(*a, **kw)
+        main.wait_event(e1)
 
     # ------------------------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -568,7 +605,13 @@ class Engine:
         def run():
             ops.gemm_tn(dY, X, G, Ni, Nj, rows, m_range=m_range, splits=splits, slab=self.slab if splits > 1 else None,
                         ldp=ldp, ldq=ldq, ldc=Nj)
-        if self.side is None:
+        if self.pair_stream is not None:
+            # paired mode: at most one weight-gradient GEMM is held back, to run beside the next LayerNorm backward (_ln_bwd);
+            # an older one goes out now, in launch order
+            if self._pend is not None:
+                self._pend()
+            self._pend = run
+        elif self.side is None:
             run()
         else:
             ev = torch.cuda.Event()
@@ -764,7 +807,7 @@ class Engine:
             ops.swiglu_bwd(w["ab"], dh, dab, rows, Fp)
         self._lin_bwd(f"{pre}.mlp.fc13", dab, w["ln2"], dln, rows)
         nb = self._ring_next()
-        ops.layernorm_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],
+        self._ln_bwd(dln, xin[:rows], w["st2"][0], w["st2"][1], self.p[f"{pre}.norm2.weight"], dres, self.g[f"{pre}.norm2.weight"],
                           dx_in=dres, dx_bf16=nb, width=self.Dl)
         return nb
 
@@ -777,7 +820,7 @@ class Engine:
                        o_lo=w["ao_lo"], **(groups or {}))
         self._lin_bwd(f"{pre}.{attn_name}.qkv.weight", dqkv, w["ln1"], dln, rows)
         nb = self._ring_next()
-        ops.layernorm_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
+        self._ln_bwd(dln, w["x"][:rows], w["st1"][0], w["st1"][1], self.p[f"{pre}.norm1.weight"], dres, self.g[f"{pre}.norm1.weight"],
                           dx_in=dres, dx_bf16=nb, width=self.Dl)
         return nb
 
@@ -844,13 +887,13 @@ class Engine:
                            1, 0, B, M, N, o_lo=w["xo_lo"])
             self._lin_bwd(f"{pre}.cross_attn.q.weight", dq, w["qn"], dln, RM)
             nb = self._ring_next()
-            ops.layernorm_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
+            self._ln_bwd(dln, w["x1"][:RM], w["stq"][0], w["stq"][1], self.p[f"{pre}.query_norm.weight"], dres,
                               self.g[f"{pre}.query_norm.weight"], dx_in=dres, dx_bf16=nb, width=self.Dl)
             dres_b = nb
             dcn = self.dcn[i] if fused else self.t_d3    # not t_d2: dq is still being read by the q-projection wgrad on the side stream
             self._lin_bwd(f"{pre}.cross_attn.kv.weight", dkv, w["cn"], dcn, RN)
             if not fused:
-                ops.layernorm_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
+                self._ln_bwd(dcn, self.ctx[:RN], w["stc"][0], w["stc"][1], self.p[f"{pre}.context_norm.weight"], self.dctx,
                                   self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
             first_ctx = False
             dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"], groups=self._dec_groups())
@@ -883,7 +926,7 @@ class Engine:
         dxe_n = self.t_d
         self._lin_bwd("decoder_proj_context.weight", self.dctx_b, self.xe, dxe_n, RN)
         dxe, dxe_b = self.dxe, self._ring_next()
-        ops.layernorm_bwd(dxe_n, self.x_enc_out[:RN], self.st_en[0], self.st_en[1], self.p["encoder_norm.weight"], dxe,
+        self._ln_bwd(dxe_n, self.x_enc_out[:RN], self.st_en[0], self.st_en[1], self.p["encoder_norm.weight"], dxe,
                           self.g["encoder_norm.weight"], dx_in=None, dx_bf16=dxe_b, width=self.Dl)
         done("bridge")
 

@@ -254,7 +254,7 @@ class GenerationSampler:
             total_u = int(sum(n_in[n] + dec_so_far[n] for n in unc).max()) if unc else 0
             plan.append(dict(target=t, n_dec=n_dec, n_enc_cond=total, guided=guided, n_enc_uncond=total_u, info=info))
             dec_so_far[t] += n_dec
-        key = ("generate", B, tuple(names), tuple((n, tuple(int(x) for x in n_in[n])) for n in names), tuple(sorted(n_open.items())), float(top_p),
+        key = ("generate", bool(eng.cfg_pair), B, tuple(names), tuple((n, tuple(int(x) for x in n_in[n])) for n in names), tuple(sorted(n_open.items())), float(top_p),
                tuple((p["target"], p["n_dec"], p["info"]["temperature"], p["info"].get("cfg_scale", 1.0),
                       tuple(p["info"].get("cfg_cond_domains", []))) for p in plan))
         graphs = eng.__dict__.setdefault("_graphs", {})
