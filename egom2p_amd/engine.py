@@ -34,6 +34,15 @@ I32 = torch.int32
 
 
 _PAIR_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_WARM_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def warmup_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """The side stream graph captures warm up on: one per device and process (a stream is a hardware queue)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _WARM_STREAMS:
+        _WARM_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _WARM_STREAMS[key]
 
 
 def _pad128(n: int) -> int:
@@ -1162,7 +1171,7 @@ class Engine:
             while len(graphs) >= self.max_graphs:
                 graphs.pop(next(iter(graphs)))
             st = make_state()
-            side = torch.cuda.Stream(device=self.dev)
+            side = warmup_stream(self.dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                           # warm-up (lazy inits happen here, not in the capture)
                 run(st)

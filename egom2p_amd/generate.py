@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .engine import warmup_stream
 
 
 # ---------------------------------------------------------------------------------------------- schedules
@@ -283,7 +284,7 @@ class GenerationSampler:
                                                     n_enc_uncond=p["n_enc_uncond"], ws=st["ws"]))
                 return md
 
-            side = torch.cuda.Stream(device=eng.dev)
+            side = warmup_stream(eng.dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up outside the capture (lazy initialisations)
                 run()
