@@ -45,6 +45,26 @@ def warmup_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _WARM_STREAMS[key]
 
 
+def head_layout(H: int, HD: int, min_pad: int = 0) -> Tuple[int, int]:
+    """(elements between two stored heads, heads in storage) for H heads of dimension HD.
+
+    Heads of 64 are stored as they are (the throughput attention kernels); A = H * 64 is the N / K extent of the qkv / proj
+    GEMMs and the pitch of the [rows, A] buffers, which the kernels are validated for in multiples of 128 only: an odd head
+    count (dim 960 = 15 x 64) is refused.  Other head dimensions are zero-padded to 96 or 128 (ego_attn_*_hd kernels) and, where
+    that makes A a multiple of 128 with narrower rows, an all-zero PHANTOM head is appended: the registered ego-L (15 heads of
+    68) is 16 x 96 = 1536 wide - the phantom head's q = k = v = 0 give a uniform softmax over zero values, output and every
+    gradient through it exactly 0 - where 15 x 128 = 1920 cost 25 % more attention and qkv / proj GEMM work.
+    min_pad (EGOM2P_HEAD_PAD) = 128 keeps the round-3 layout."""
+    if HD == 64:
+        if (H * 64) % 128:
+            raise L.EgoHipError(f"heads of 64 need an even head count (heads={H}: A = {H * 64} is not a multiple of 128)")
+        return 64, H
+    fits = sorted((next(n for n in range(H, H + 9) if (n * h) % 128 == 0) * h, h) for h in (96, 128) if h >= HD and h >= min_pad)
+    if not fits:
+        raise L.EgoHipError(f"no storage layout for {H} heads of {HD}")
+    return fits[0][1], fits[0][0] // fits[0][1]
+
+
 def _pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 
@@ -89,24 +109,7 @@ class Engine:
         self.dev = torch.device(device)
         self.Dl, self.D, self.H = cfg.dim, _pad128(cfg.dim), cfg.num_heads
         self.HD = cfg.head_dim
-        if self.HD == 64:
-            self.HDP = 64
-            if (self.H * 64) % 128:
-                # A = H * 64 is the N / K extent of the qkv / proj GEMMs and the pitch of the [rows, A] buffers: the kernels are
-                # validated for multiples of 128 only (an odd head count, e.g. dim 960 = 15 x 64, would need padded heads)
-                raise L.EgoHipError(f"heads of 64 need an even head count (dim={cfg.dim}, heads={cfg.num_heads}: A = {self.H * 64} is not a multiple of 128)")
-        self.Hs = self.H                      # heads in storage: >= H (all-zero phantom heads make A a multiple of 128)
-        if self.HD != 64:
-            # (pad, stored heads) with the narrowest rows: the registered ego-L (15 heads of 68) is 16 x 96 = 1536 wide - one
-            # all-zero phantom head (q = k = v = 0: uniform softmax over zero values, output and every gradient exactly 0)
-            # costs 1/16 of the attention work, 15 x 128 = 1920 cost 25 % of it and of the qkv / proj GEMMs.
-            # EGOM2P_HEAD_PAD=128 keeps the round-3 layout.
-            pads = [h for h in (96, 128) if h >= self.HD and h >= int(os.environ.get("EGOM2P_HEAD_PAD", "0"))]
-            fits = sorted((next(n for n in range(self.H, self.H + 9) if (n * h) % 128 == 0) * h, h) for h in pads)
-            if not fits:
-                raise L.EgoHipError(f"no storage layout for dim={cfg.dim}, heads={cfg.num_heads} x {self.HD}")
-            self.HDP = fits[0][1]
-            self.Hs = fits[0][0] // self.HDP
+        self.HDP, self.Hs = head_layout(cfg.num_heads, cfg.head_dim, int(os.environ.get("EGOM2P_HEAD_PAD", "0")))
         self.A = self.Hs * self.HDP
         self.padded = self.D != self.Dl or self.HDP != self.HD or self.Hs != self.H
         if self.padded and fp8_forward:

@@ -82,3 +82,22 @@ def test_bench_counts_the_flops_the_survey_states():
     f = bench.flops_per_clip(MODEL_CFGS["egom2p_base_12e_12d_swiglu_nobias"], synth.CANONICAL_BUDGETS, 2048, 2048)
     assert abs(f / 1.397e12 - 1.0) < 1e-3
     assert abs(3.0 * f / 10300 / 406.9e6 - 1.0) < 1e-3
+
+
+def test_head_storage_layouts():
+    """Host logic of the padded storage (engine.head_layout): heads of 64 unchanged (even counts only); other head dimensions
+    padded to 96 / 128 with as many all-zero phantom heads as make the row width a multiple of 128 - the narrowest rows win."""
+    import pytest
+    from egom2p_amd.engine import head_layout
+    assert head_layout(12, 64) == (64, 12) and head_layout(18, 64) == (64, 18)          # ego-b, ego-L (D = 1152)
+    assert head_layout(15, 68) == (96, 16)              # registered ego-L (egom2p_model.py:1080-1092): 1536 wide, one phantom head
+    assert head_layout(15, 68, min_pad=128) == (128, 15)                                # EGOM2P_HEAD_PAD=128: the round-3 layout
+    assert head_layout(31, 66) == (96, 32)              # registered ego-XL (:1100-1118)
+    assert head_layout(16, 120) == (128, 16) and head_layout(4, 96) == (96, 4)
+    for H, HD in ((15, 64), (4, 200)):
+        with pytest.raises(L.EgoHipError):
+            head_layout(H, HD)
+    for H in range(1, 40):                              # whatever the head count: rows are multiples of 128, at most 8 phantom heads
+        for HD in (66, 68, 80, 96, 100, 128):
+            hdp, hs = head_layout(H, HD)
+            assert hdp >= HD and hs >= H and hs - H <= 8 and (hdp * hs) % 128 == 0
