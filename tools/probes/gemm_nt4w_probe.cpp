@@ -1,0 +1,229 @@
+// Probe (round 4): a 4-wave NT GEMM - C[M, N] (bf16) = A[M, K] B[N, K]^T - with 128 x 128 outputs per wave (256 fp32 accumulators
+// per lane: the AGPR half of a 512-register wave, ONE wave per SIMD) against the product's 8-wave 256 x 256 kernel (wave tile
+// 128 x 64).  Question: do two thirds of the LDS fragment reads per MFMA (16 ds_read_b128 per 64 MFMAs instead of 12 per 32) and a
+// one-wave instruction stream get closer to the vendor library on the long-K shapes (profiles/r04_gemm_vs_vendor_library.log)?
+//
+//   tile 256 x 256 x 32 per K-step, 5 LDS stages of 32 KB (A and B, 64-byte rows, 16-byte chunks swizzled on the source:
+//   slot (c ^ f[(row >> 2) & 3]), f = {0, 3, 2, 1}: conflict-free for the four 16-lane groups of ds_read_b128), LDS-DMA two K-steps
+//   ahead of the step whose fragments are being read, fragments one K-step ahead of the MFMAs (two register sets).
+//   One tile per workgroup (no persistence): the probe is about the main loop, run it on K >= 2048.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o gemm_nt4w_probe tools/probes/gemm_nt4w_probe.cpp && ./gemm_nt4w_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <cmath>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short bf16_t;
+
+// timing-only ablations (results are wrong): -DABL_NOLOAD=1 leaves the LDS-DMA out of the steady state, -DABL_NOBAR=1 the barrier
+#ifndef ABL_NOLOAD
+#define ABL_NOLOAD 0
+#endif
+#ifndef ABL_NOBAR
+#define ABL_NOBAR 0
+#endif
+constexpr int BM = 256, BN = 256, BK = 32, STAGES = 5;
+constexpr int TILE_BYTES = 256 * 64;              // one operand tile of a stage: 256 rows x 32 bf16
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B = 32 KB
+constexpr int LDS_BYTES = STAGES * STAGE_BYTES;   // 160 KB: the whole LDS of a CU - four stages (128 KB) in flight
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+__device__ __forceinline__ int swz(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }   // f = {0, 3, 2, 1}
+
+struct Args { const bf16_t* A; const bf16_t* B; bf16_t* C; int M, N, K; };
+
+__global__ __launch_bounds__(256) void gemm_nt4w_kernel(Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = p.N / BN;
+    // XCD-aware order: every XCD gets a contiguous run of tile ids (column tiles of one row tile share the A rows in its L2)
+    const int nwg = gridDim.x, q = nwg >> 3, r8 = nwg & 7, x = blockIdx.x & 7, i8 = blockIdx.x >> 3;
+    const int tile = (x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q) + i8;
+    const int row0 = (tile / tiles_n) * BM, col0 = (tile % tiles_n) * BN;
+    const int nt = p.K / BK;
+
+    // staging: wave instruction j of wave w fills tile rows 16 (4 w + j) .. +15 (1 KB, lane-linear: lane -> row lane >> 2, slot lane & 3)
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 16 * (4 * wave + j) + (lane >> 2);
+        const int c = ((lane & 3) ^ swz(r)) * 8;
+        ga[j] = p.A + (long)(row0 + r) * p.K + c;
+        gb[j] = p.B + (long)(col0 + r) * p.K + c;
+    }
+    auto stage = [&](int s, int k0) {
+        char* sa = smem + s * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(ga[j] + k0, sa + j * 1024);
+            glds16(gb[j] + k0, sa + TILE_BYTES + j * 1024);
+        }
+    };
+    // fragment addresses inside a stage: m-tile i of this wave, row lane & 15, logical chunk lane >> 4
+    int a_off[8], b_off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ar = wm * 128 + i * 16 + (lane & 15), br = wn * 128 + i * 16 + (lane & 15);
+        a_off[i] = ar * 64 + (((lane >> 4) ^ swz(ar)) << 4);
+        b_off[i] = TILE_BYTES + br * 64 + (((lane >> 4) ^ swz(br)) << 4);
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Two fragment sets, addressed with compile-time indices only (a run-time set index would put them in scratch).  The MFMAs and
+    // the fragment reads are inline asm: accumulators pinned to AGPRs ("+a": through the builtin hipcc moves them between the
+    // register files around every group once anything is interleaved), and the instruction order is the one written here -
+    // one wave per SIMD has nobody else to issue MFMAs while it issues memory instructions, so every K-step spreads its 8
+    // LDS-DMA issues and 16 fragment reads over the 64 MFMAs.
+    bf16x8 af0[8], bf0[8], af1[8], bf1[8];
+#define DSREAD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory")
+#define MFMA(c, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a_), "v"(b_))
+    // K-step kt: stage kt + 1 has landed for every wave (vmcnt + barrier; the barrier also says that every wave is past the MFMAs
+    // that read stage kt - 1's slot), its fragments are read into the other set while this set feeds the MFMAs, stage kt + 3 leaves
+    // global memory.  LOADS = 0 in the last steps (nothing left to fetch), NEXT = 0 in the very last one.
+#define STEP(AFC, BFC, AFN, BFN, kt, LOADS, NEXT, VMW)                                                       \
+    do {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(" #VMW ") lgkmcnt(0)" ::: "memory");                                  \
+        if (!ABL_NOBAR) __builtin_amdgcn_s_barrier();                                                       \
+        /* this step's own slot is free: its fragments were read during the previous step (every wave: lgkmcnt + barrier) */ \
+        char* sa_ = smem + slot * STAGE_BYTES + wave * 4096;                                                \
+        slot = slot + 1 == STAGES ? 0 : slot + 1;                                                           \
+        const unsigned sf_ = (unsigned)(slot * STAGE_BYTES);                                                \
+        const int k0_ = ((kt) + STAGES) * BK;                                                               \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                     \
+            if (LOADS && !ABL_NOLOAD) {                                                                     \
+                if (r & 1) glds16(gb[r >> 1] + k0_, sa_ + TILE_BYTES + (r >> 1) * 1024);                    \
+                else glds16(ga[r >> 1] + k0_, sa_ + (r >> 1) * 1024);                                       \
+            }                                                                                               \
+            if (NEXT) { DSREAD(AFN[r], lds0 + sf_ + a_off[r]); }                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) MFMA(acc[r][j], BFC[j], AFC[r]);                  \
+            if (NEXT) { DSREAD(BFN[r], lds0 + sf_ + b_off[r]); }                                            \
+            _Pragma("unroll") for (int j = 4; j < 8; ++j) MFMA(acc[r][j], BFC[j], AFC[r]);                  \
+        }                                                                                                   \
+    } while (0)
+
+    // prologue: stages 0 .. 4 in flight, stage 0's fragments read
+    const unsigned lds0 = (unsigned)(size_t)smem;          // (LDS addresses are 32-bit offsets)
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) stage(s, s * BK);
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { DSREAD(af0[r], lds0 + a_off[r]); DSREAD(bf0[r], lds0 + b_off[r]); }
+
+    int kt = 0, slot = 0;                                // nt = K / 32 is even and >= 8 here (K % 64 == 0, K >= 256)
+    for (; kt + 6 < nt; kt += 2) {
+        STEP(af0, bf0, af1, bf1, kt, 1, 1, 24);          // operands swapped in the MFMA: D[row = n (4 regs)][col = m (lane & 15)]
+        STEP(af1, bf1, af0, bf0, kt + 1, 1, 1, 24);
+    }
+    // kt = nt - 6: stages nt - 5 .. nt - 2 are in flight, nt - 1 is still to be issued
+    STEP(af0, bf0, af1, bf1, kt, 1, 1, 24);
+    STEP(af1, bf1, af0, bf0, kt + 1, 0, 1, 24);
+    STEP(af0, bf0, af1, bf1, kt + 2, 0, 1, 16);
+    STEP(af1, bf1, af0, bf0, kt + 3, 0, 1, 8);
+    STEP(af0, bf0, af1, bf1, kt + 4, 0, 1, 0);
+    STEP(af1, bf1, af0, bf0, kt + 5, 0, 0, 0);
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gm = row0 + wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gn = col0 + wn * 128 + j * 16 + 4 * (lane >> 4);
+            const f32x4 v = acc[i][j];
+            *(u32x2*)(p.C + (long)gm * p.N + gn) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+    }
+}
+
+// reference on a sample of outputs
+__global__ void ref_kernel(Args p, const int* rows, const int* cols, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bf16_t* a = p.A + (long)rows[i] * p.K;
+    const bf16_t* b = p.B + (long)cols[i] * p.K;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) s += __uint_as_float((unsigned)a[k] << 16) * __uint_as_float((unsigned)b[k] << 16);
+    out[i] = s;
+}
+
+static bf16_t f2b(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+static float b2f(bf16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main() {
+    hipFuncSetAttribute((const void*)gemm_nt4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    struct Shape { const char* name; int M, N, K; };
+    const Shape shapes[] = {{"fc2", 131072, 768, 2048}, {"dgrad qkv", 131072, 768, 2304}, {"dgrad fc13", 131072, 768, 4096},
+                            {"dgrad fc2", 131072, 2048, 768}, {"qkv", 131072, 2304, 768}, {"square 8192", 8192, 8192, 8192}};
+    const char* only = getenv("PROBE_SHAPE");            // e.g. PROBE_SHAPE="dgrad fc13"; PROBE_NOCHECK=1 skips the sampled check (profiler runs)
+    const bool nocheck = getenv("PROBE_NOCHECK") != nullptr;
+    for (const Shape& sh : shapes) {
+        if (only && strcmp(only, sh.name) != 0) continue;
+        const long na = (long)sh.M * sh.K, nb = (long)sh.N * sh.K, nc = (long)sh.M * sh.N;
+        std::vector<bf16_t> ha(na), hb(nb);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+        for (long i = 0; i < na; ++i) ha[i] = f2b(rnd());
+        for (long i = 0; i < nb; ++i) hb[i] = f2b(rnd());
+        bf16_t *A, *B, *C;
+        hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2); hipMalloc(&C, nc * 2);
+        hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice);
+        hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
+        Args a{A, B, C, sh.M, sh.N, sh.K};
+        const dim3 grid((sh.M / BM) * (sh.N / BN));
+        hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", sh.name); return 1; }
+        // check 4096 sampled outputs
+        const int n = 4096;
+        std::vector<int> hr(n), hc(n);
+        for (int i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; hr[i] = (s >> 4) % sh.M; s = s * 1664525u + 1013904223u; hc[i] = (s >> 4) % sh.N; }
+        int *dr, *dc; float* dref;
+        hipMalloc(&dr, n * 4); hipMalloc(&dc, n * 4); hipMalloc(&dref, n * 4);
+        hipMemcpy(dr, hr.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dc, hc.data(), n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(ref_kernel, dim3(n / 256), dim3(256), 0, 0, a, dr, dc, n, dref);
+        std::vector<float> href(n);
+        hipMemcpy(href.data(), dref, n * 4, hipMemcpyDeviceToHost);
+        double worst = 0;
+        for (int i = 0; i < (nocheck ? 0 : n); ++i) {
+            bf16_t got;
+            hipMemcpy(&got, C + (long)hr[i] * sh.N + hc[i], 2, hipMemcpyDeviceToHost);
+            const double e = fabs(b2f(got) - href[i]) / (fabs(href[i]) + 1.0);
+            if (e > worst) worst = e;
+        }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int rnd_i = 0; rnd_i < 5; ++rnd_i) {
+            hipEventRecord(e0);
+            for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms / 10 < best) best = ms / 10;
+        }
+        printf("NT4W %-12s M=%d N=%d K=%d: %8.1f us = %7.1f TF/s   (worst sampled rel err %.2e)\n", sh.name, sh.M, sh.N, sh.K, best * 1e3,
+               2.0 * sh.M * sh.N * sh.K / (best * 1e-3) / 1e12, worst);
+        fflush(stdout);
+        hipFree(A); hipFree(B); hipFree(C); hipFree(dr); hipFree(dc); hipFree(dref);
+    }
+    return 0;
+}
