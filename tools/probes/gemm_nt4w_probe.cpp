@@ -157,6 +157,107 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same loop with EIGHT waves (two per SIMD, wave tile 128 x 64, 128 accumulators in VGPRs): no ping-pong phases, one barrier
+// per K-step; whenever one wave of a SIMD issues its DMA pieces or fragment reads, the other one has MFMAs to issue.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_nt8w_kernel(Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x, q = nwg >> 3, r8 = nwg & 7, x = blockIdx.x & 7, i8 = blockIdx.x >> 3;
+    const int tile = (x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q) + i8;
+    const int row0 = (tile / tiles_n) * BM, col0 = (tile % tiles_n) * BN;
+    const int nt = p.K / BK;
+    // staging: wave w fills tile rows 32 w .. 32 w + 31 of A and of B (two 1 KB pieces each)
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * (2 * wave + j) + (lane >> 2);
+        const int c = ((lane & 3) ^ swz(r)) * 8;
+        ga[j] = p.A + (long)(row0 + r) * p.K + c;
+        gb[j] = p.B + (long)(col0 + r) * p.K + c;
+    }
+    unsigned a_off[8], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ar = wm * 128 + i * 16 + (lane & 15);
+        a_off[i] = ar * 64 + (((lane >> 4) ^ swz(ar)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int br = wn * 64 + i * 16 + (lane & 15);
+        b_off[i] = TILE_BYTES + br * 64 + (((lane >> 4) ^ swz(br)) << 4);
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af0[8], bf0[4], af1[8], bf1[4];
+#define MFMAV(c, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a_), "v"(b_))
+#define STEP8(AFC, BFC, AFN, BFN, kt, LOADS, NEXT, VMW)                                                      \
+    do {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(" #VMW ") lgkmcnt(0)" ::: "memory");                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        char* sa_ = smem + slot * STAGE_BYTES + wave * 2048;                                                \
+        slot = slot + 1 == STAGES ? 0 : slot + 1;                                                           \
+        const unsigned sf_ = (unsigned)(slot * STAGE_BYTES);                                                \
+        const int k0_ = ((kt) + STAGES) * BK;                                                               \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                     \
+            if (LOADS) {                                                                                    \
+                if (r & 1) glds16(gb[r >> 1] + k0_, sa_ + TILE_BYTES + (r >> 1) * 1024);                    \
+                else glds16(ga[r >> 1] + k0_, sa_ + (r >> 1) * 1024);                                       \
+            }                                                                                               \
+            if (NEXT) { DSREAD(AFN[2 * r], lds0 + sf_ + a_off[2 * r]); }                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) MFMAV(acc[2 * r][j], BFC[j], AFC[2 * r]);         \
+            if (NEXT) { DSREAD(AFN[2 * r + 1], lds0 + sf_ + a_off[2 * r + 1]); DSREAD(BFN[r], lds0 + sf_ + b_off[r]); } \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) MFMAV(acc[2 * r + 1][j], BFC[j], AFC[2 * r + 1]); \
+        }                                                                                                   \
+    } while (0)
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto stage = [&](int s, int k0) {
+        char* sa = smem + s * STAGE_BYTES + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(ga[j] + k0, sa + j * 1024);
+            glds16(gb[j] + k0, sa + TILE_BYTES + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) stage(s, s * BK);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // 4 pieces per wave and stage: stage 0 has landed
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) DSREAD(af0[r], lds0 + a_off[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) DSREAD(bf0[r], lds0 + b_off[r]);
+    int kt = 0, slot = 0;
+    for (; kt + 6 < nt; kt += 2) {
+        STEP8(af0, bf0, af1, bf1, kt, 1, 1, 12);
+        STEP8(af1, bf1, af0, bf0, kt + 1, 1, 1, 12);
+    }
+    STEP8(af0, bf0, af1, bf1, kt, 1, 1, 12);
+    STEP8(af1, bf1, af0, bf0, kt + 1, 0, 1, 12);
+    STEP8(af0, bf0, af1, bf1, kt + 2, 0, 1, 8);
+    STEP8(af1, bf1, af0, bf0, kt + 3, 0, 1, 4);
+    STEP8(af0, bf0, af1, bf1, kt + 4, 0, 1, 0);
+    STEP8(af1, bf1, af0, bf0, kt + 5, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gm = row0 + wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = col0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+            const f32x4 v = acc[i][j];
+            *(u32x2*)(p.C + (long)gm * p.N + gn) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+    }
+}
+
 // reference on a sample of outputs
 __global__ void ref_kernel(Args p, const int* rows, const int* cols, int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +274,8 @@ static float b2f(bf16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f,
 
 int main() {
     hipFuncSetAttribute((const void*)gemm_nt4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    const bool w8 = getenv("PROBE_WAVES") && atoi(getenv("PROBE_WAVES")) == 8;
     struct Shape { const char* name; int M, N, K; };
     const Shape shapes[] = {{"fc2", 131072, 768, 2048}, {"dgrad qkv", 131072, 768, 2304}, {"dgrad fc13", 131072, 768, 4096},
                             {"dgrad fc2", 131072, 2048, 768}, {"qkv", 131072, 2304, 768}, {"square 8192", 8192, 8192, 8192}};
@@ -192,7 +295,8 @@ int main() {
         hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
         Args a{A, B, C, sh.M, sh.N, sh.K};
         const dim3 grid((sh.M / BM) * (sh.N / BN));
-        hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
+        if (w8) hipLaunchKernelGGL(gemm_nt8w_kernel, grid, dim3(512), LDS_BYTES, 0, a);
+        else hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", sh.name); return 1; }
         // check 4096 sampled outputs
         const int n = 4096;
@@ -215,12 +319,15 @@ int main() {
         float best = 1e30f;
         for (int rnd_i = 0; rnd_i < 5; ++rnd_i) {
             hipEventRecord(e0);
-            for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
+            for (int it = 0; it < 10; ++it) {
+                if (w8) hipLaunchKernelGGL(gemm_nt8w_kernel, grid, dim3(512), LDS_BYTES, 0, a);
+                else hipLaunchKernelGGL(gemm_nt4w_kernel, grid, dim3(256), LDS_BYTES, 0, a);
+            }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms / 10 < best) best = ms / 10;
         }
-        printf("NT4W %-12s M=%d N=%d K=%d: %8.1f us = %7.1f TF/s   (worst sampled rel err %.2e)\n", sh.name, sh.M, sh.N, sh.K, best * 1e3,
+        printf("%s %-12s M=%d N=%d K=%d: %8.1f us = %7.1f TF/s   (worst sampled rel err %.2e)\n", w8 ? "NT8W" : "NT4W", sh.name, sh.M, sh.N, sh.K, best * 1e3,
                2.0 * sh.M * sh.N * sh.K / (best * 1e-3) / 1e12, worst);
         fflush(stdout);
         hipFree(A); hipFree(B); hipFree(C); hipFree(dr); hipFree(dc); hipFree(dref);
