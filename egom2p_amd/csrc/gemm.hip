@@ -576,32 +576,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             if (fb) cursorB();
             // ---- phase 0: quadrant (0,0)
             LOAD_A(0) LOAD_B(0)
-            if (grp == 1 && fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
+            // (the 8 DMA pieces of a wave are spread 2 / 2 / 2 / 2 over the four load phases: 3 + 3 + 2 + 0 made the fullest load
+            //  phase outlast the other group's 32 MFMAs - a piece costs 60 - 185 issue cycles; group 0 may not touch the B slot before
+            //  phase 1 (group 1, one barrier behind, still reads it in the previous step's last phase), the A slot is free at once)
+            if (grp == 1) { if (fb) { dmaB(sB, 0); dmaB(sB, 1); } } else if (fa) { dmaA(sA, 0); dmaA(sA, 1); }
             bar_pinned();
             COMPUTE(0, 0)
             bar_pinned();
             // ---- phase 1: quadrant (0,1)
             LOAD_B(1)
-            if (grp == 1) { if (fb) dmaB(sB, 3); if (fa) { dmaA(sA, 0); dmaA(sA, 1); } }
-            else if (fb) { dmaB(sB, 0); dmaB(sB, 1); dmaB(sB, 2); }
+            if (fb) { if (grp == 1) { dmaB(sB, 2); dmaB(sB, 3); } else { dmaB(sB, 0); dmaB(sB, 1); } }
             bar_pinned();
             COMPUTE(0, 1)
             bar_pinned();
             // ---- phase 2: quadrant (1,1)
             LOAD_A(1)
-            if (grp == 1) { if (fa) { dmaA(sA, 2); dmaA(sA, 3); } }
-            else { if (fb) dmaB(sB, 3); if (fa) { dmaA(sA, 0); dmaA(sA, 1); } }
+            if (grp == 1) { if (fa) { dmaA(sA, 0); dmaA(sA, 1); } } else if (fb) { dmaB(sB, 2); dmaB(sB, 3); }
             bar_pinned();
             COMPUTE(1, 1)
             bar_pinned();
             // ---- phase 3: quadrant (1,0)
             LOAD_B(0)
-            if (grp == 0 && fa) { dmaA(sA, 2); dmaA(sA, 3); }
-            // G1: B(g+1) and the older A(g+1) landed before slot 7 closes; its 4 pieces of A(g+2) may stay in flight
+            if (fa) { dmaA(sA, 2); dmaA(sA, 3); }
+            // G1: B(g+1) and the older A(g+1) landed before slot 7 closes; its 4 pieces of A(g+2) (the youngest) may stay in flight
             if (grp == 1) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
             COMPUTE(1, 0)
-            if (grp == 0) { if (fa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            // G0 issued A(g+2) pieces 0, 1 first, then B(g+1), then A(g+2) pieces 2, 3: everything but the last two has landed
+            if (grp == 0) { if (fa) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             bar_pinned();
             if (fa) advanceA();
             if (fb) advanceB();
@@ -1172,6 +1174,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
             const int m1 = (st + 1) * BK, m2 = (st + 2) * BK;
             const bool fp = st + 1 < st1, fq = st + 2 < st1;
             TLOAD_P(0, soP) TLOAD_Q(q0, 0, soQ)
+            // (pieces 3 / 3 / 2 / 0 per group: the 2 / 2 / 2 / 2 spread that helps gemm_nt256_kernel measured 2.7 % SLOWER here)
             if (grp == 1 && fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); }
             bar_pinned();
             TCOMPUTE(q0, 0, 0)
