@@ -1174,20 +1174,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs p) {
             const int m1 = (st + 1) * BK, m2 = (st + 2) * BK;
             const bool fp = st + 1 < st1, fq = st + 2 < st1;
             TLOAD_P(0, soP) TLOAD_Q(q0, 0, soQ)
-            // (pieces 3 / 3 / 2 / 0 per group: the 2 / 2 / 2 / 2 spread that helps gemm_nt256_kernel measured 2.7 % SLOWER here)
-            if (grp == 1 && fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); }
+            // (DMA pieces per load phase: all four of P(g+1) - the 2-deep ring, needed next step - in the first phase a group may
+            //  touch that slot, then Q(g+2) 2 + 2: 4 / 2 / 2 / 0 for group 1, 0 / 4 / 2 / 2 for group 0.  +1 ... 2 % over 3 / 3 / 2 / 0;
+            //  the 2 / 2 / 2 / 2 spread that helps gemm_nt256_kernel measured 2.7 % SLOWER here: profiles/r04_gemm_dma_schedules.log)
+            if (grp == 1 && fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); dmaP(spn, m1, 3); }
             bar_pinned();
             TCOMPUTE(q0, 0, 0)
             bar_pinned();
             TLOAD_Q(qf, 1, soQ)
-            if (grp == 1) { if (fp) dmaP(spn, m1, 3); if (fq) { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
-            else if (fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); }
+            if (grp == 1) { if (fq) { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
+            else if (fp) { dmaP(spn, m1, 0); dmaP(spn, m1, 1); dmaP(spn, m1, 2); dmaP(spn, m1, 3); }
             bar_pinned();
             TCOMPUTE(qf, 0, 1)
             bar_pinned();
             TLOAD_P(1, soP)
-            if (grp == 1) { if (fq) { dmaQ(sqn, m2, 2); dmaQ(sqn, m2, 3); } }
-            else { if (fp) dmaP(spn, m1, 3); if (fq) { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
+            if (fq) { if (grp == 1) { dmaQ(sqn, m2, 2); dmaQ(sqn, m2, 3); } else { dmaQ(sqn, m2, 0); dmaQ(sqn, m2, 1); } }
             bar_pinned();
             TCOMPUTE(qf, 1, 1)
             bar_pinned();
