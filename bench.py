@@ -44,8 +44,8 @@ def cpu_baseline(cfg, sd, synth, budgets, rank, order, n_enc, n_dec, protocol):
     """The oracle (CPU restatement of the reference's forward, validated against the reference's own outputs) timed on
     the host cores: forward + backward of whole clips of the same workload.  SURVEY.md section 8(d) protocol = one
     warm-up, then the median of 5 runs, for B in {1, 4}, in fp32 and in the autocast-emulating bf16 mode ("full",
-    ~15 min); the default ("quick") keeps the bench within minutes: one warm-up + median of 3 at B = 1 fp32, one run of
-    bf16 mode.  `value` is always the B = 1 fp32 median."""
+    ~20 min); the default ("survey-fp32") runs the fp32 legs of that protocol under a budget of CPU seconds (~5 min); "quick":
+    one warm-up + median of 3 at B = 1 fp32, one run of bf16 mode.  `value` is always the B = 1 fp32 median."""
     import statistics
     from oracle import egom2p_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -60,29 +60,42 @@ def cpu_baseline(cfg, sd, synth, budgets, rank, order, n_enc, n_dec, protocol):
         return time.time() - t0, float(loss.item())
 
     full = [(1, "fp32", 1, 5), (4, "fp32", 1, 5), (1, "bf16", 1, 5), (4, "bf16", 1, 5)]
-    plan = {"quick": [(1, "fp32", 1, 3), (1, "bf16", 0, 1)], "full": full,
+    plan = {"quick": [(1, "fp32", 1, 3), (1, "bf16", 0, 1)], "full": full, "survey-fp32": full[:2],
             "full-fp32": full[:2], "full-bf16": [full[0][:3] + (1,)] + full[2:]}[protocol]   # halves of "full" for a 20-minute box limit
-    runs, total = [], 0.0
+    # "survey-fp32" (the default): SURVEY 8(d)'s fp32 legs - one warm-up + median of 5 at B = 1 and at B = 4 - under a budget of CPU
+    # seconds so that the default run stays within minutes on a slow host: a leg stops early (never below 3 timed runs) when
+    # its next run would not fit, and the B = 4 leg is left out (and said so) when not even warm-up + 3 runs of it fit
+    budget = float(os.environ.get("EGOM2P_CPU_BASELINE_BUDGET_S", "340")) if protocol == "survey-fp32" else float("inf")
+    runs, total, notes = [], 0.0, []
+    t_clip = None                                            # seconds per clip seen so far (B = 1 fp32)
     for B, mode, n_warm, n_timed in plan:
+        if t_clip is not None and total + (n_warm + 3) * B * t_clip > budget:
+            notes.append(f"B={B} {mode} leg left out: warm-up + 3 runs (~{(n_warm + 3) * B * t_clip:.0f} s) do not fit the {budget:.0f} s budget")
+            continue
         md = synth.make_clip_batch(cfg, B, budgets, seed=100 + rank, sample_offset=0)      # the GPU run's first clips, host copy
         for _ in range(n_warm):
             total += once(md, mode)[0]
         ts, loss = [], None
         for _ in range(n_timed):
+            if len(ts) >= 3 and total + sum(ts) + ts[-1] > budget:
+                notes.append(f"B={B} {mode}: {len(ts)} of {n_timed} timed runs (budget {budget:.0f} s)")
+                break
             t, loss = once(md, mode)
             ts.append(t)
             print(f"[cpu_baseline] B={B} {mode}: {t:.1f} s", file=sys.stderr, flush=True)
         total += sum(ts)
         med = statistics.median(ts)
-        runs.append({"batch": B, "mode": mode, "warmup": n_warm, "timed": n_timed, "median_s": round(med, 3),
+        if B == 1 and mode == "fp32":
+            t_clip = med
+        runs.append({"batch": B, "mode": mode, "warmup": n_warm, "timed": len(ts), "median_s": round(med, 3),
                      "clip_positions_per_s": round(B * 10300.0 / med, 1), "loss": loss})
     head = runs[0]
+    what = {"quick": " (a bounded sample: 1 warm-up + median of 3 at B = 1 fp32 and one bf16-mode run; SURVEY 8(d)'s protocol is 'survey-fp32' / 'full')",
+            "survey-fp32": " (SURVEY 8(d): 1 warm-up + median of 5, B in {1, 4}, fp32, under a CPU-seconds budget; the bf16-mode legs are '--cpu-baseline full')"}
     return {"value": head["clip_positions_per_s"], "unit": "clip-positions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "protocol": protocol + (" (SURVEY 8(d) asks for median of 5 at B in {1, 4}, fp32 and bf16 mode = '--cpu-baseline full', ~20 min: "
-                                    "the default line carries the bounded 'quick' sample so that the run stays within minutes; box-to-box the "
-                                    "value moves 730-930 positions/s)" if protocol == "quick" else ""),
+            "protocol": protocol + what.get(protocol, ""),
             "sample": f"protocol '{protocol}': B=1 fp32 fwd+bwd of one 10300-position clip (N=M={n_enc}), {head['warmup']} warm-up + "
-                      f"median of {head['timed']} ({head['median_s']} s each); all legs {total:.0f} s of CPU work",
+                      f"median of {head['timed']} ({head['median_s']} s each); all legs {total:.0f} s of CPU work" + ("; " + "; ".join(notes) if notes else ""),
             "loss": head["loss"], "runs": runs}
 
 
@@ -254,8 +267,10 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=64,
                     help="clips per forward/backward (accumulated to --clips-per-gpu); 64 measured best on MI355X: 32 -1.5 %, 128 -0.6 %")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=["quick", "full", "full-fp32", "full-bf16"], default="quick",
-                    help="quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; full: SURVEY 8(d) protocol (~15 min)")
+    ap.add_argument("--cpu-baseline", choices=["survey-fp32", "quick", "full", "full-fp32", "full-bf16"], default="survey-fp32",
+                    help="survey-fp32 (default): SURVEY 8(d)'s fp32 legs - warm-up + median of 5 at B = 1 and B = 4 - within a budget of "
+                         "$EGOM2P_CPU_BASELINE_BUDGET_S (340) CPU seconds; quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; "
+                         "full: fp32 and bf16 mode (~20 min)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
@@ -331,8 +346,6 @@ def main():
     step = TrainStep(eng, lr=args.lr, weight_decay=0.05, clip_grad=1.0, world_size=world, seed=rank,
                      force_reducer=os.environ.get("EGOM2P_FORCE_REDUCER") == "1", clips_per_step=clips,
                      sparse_tables=args.sparse_tables, dp_algo=args.dp_algo, dp_backend=args.dp_backend)
-    if step.reducer is not None:
-        step.reducer.timing = True
 
     def run_step(i):
         return step([mbs[(i * n_mb + j) % pool] for j in range(n_mb)])
@@ -357,7 +370,16 @@ def main():
         dt = float(t.item())
     final_loss = float(losses[0].item())
 
-    par, dp_extra = dp_report(step.reducer, world, step.sparse)       # the LAST step's exchange (event-timed on the comm stream)
+    # the timed steps above ran the exchange exactly as TrainStep runs it (no per-bucket event pairs, no extra
+    # waits); exchange_ms / exposed_ms / overlap_frac come from ONE more, instrumented step outside the timed region
+    if step.reducer is not None:
+        step.reducer.timing = True
+        run_step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        step.reducer.timing = False
+    par, dp_extra = dp_report(step.reducer, world, step.sparse)       # that instrumented step's exchange (event-timed on the comm stream)
+    if dp_extra:
+        dp_extra["exchange_timing"] = "one instrumented step after the timed region (the timed steps run uninstrumented)"
     ms_per_step = dt / args.steps * 1e3
     tokens = world * clips * 10300 * args.steps
     value = tokens / dt
@@ -388,6 +410,10 @@ def main():
         with kt.capture(cfg.num_heads):
             eng.forward(mbs[0], dec_order=[m.name for m in cfg.mods], loss_grad=1.0)
             eng.backward(1.0)
+            if world == 1:
+                # the optimiser side of a step (clip norm, AdamW with zero_grad folded in, the bf16 weight copies): HBM-bound too
+                step.opt.step(clip_grad=1.0, zero_grad=True)
+                eng.refresh_weights()
         eng.pair_stream = pair
         eng.zero_grad()
         summ = kt.summary()
@@ -414,9 +440,33 @@ def main():
                                                    f"({pmc.get('kernel_src_sha')} vs {kernel_source_sha()}): re-run tools/pmc_run.sh")
         out["roofline"]["algorithmic_bytes_per_launch"] = dom[1]["bytes"] / dom[1]["calls"]
         # north_star's HBM-bound paths (embedding / masking / scatter / normalisation / loss): algorithmic GB/s vs the HBM roof
+        # `gbs` = ALGORITHMIC bytes / HIP-event time (what the path has to move); `traffic` = bytes per call that left the L2s by the
+        # PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_latest.json, same kernel sources and micro-batch only) and
+        # `frac` = traffic / time / 8 TB/s.  Requests served by the 256 MB Infinity Cache are counted by FETCH_SIZE
+        # (MI355X_MICROARCH.md, HBM): a frac above ~0.79 (6.3 TB/s is what HBM delivers) says part of the bytes never reached HBM.
         hbm = {k: v for k, v in summ.items() if v["flops"] == 0 and v["bytes"] > 0}
-        out["hbm_paths"] = {k: {"gbs": round(v["gbs"], 1), "frac_of_8TBs": round(v["gbs"] / PEAK_HBM_GBS, 3), "us_per_call": round(1e3 * v["ms"] / v["calls"], 1)}
-                            for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}
+        pmc_abi = {}
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if (pmc.get("kernel_src_sha") == kernel_source_sha() and pmc.get("micro_batch") == mb
+                    and args.model == "egom2p_base_12e_12d_swiglu_nobias"):
+                pmc_abi = pmc.get("abi", {})
+        out["hbm_paths"] = {}
+        for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"]):
+            us = 1e3 * v["ms"] / v["calls"]
+            ent = {"gbs": round(v["gbs"], 1), "algorithmic_bytes_per_call": round(v["bytes"] / v["calls"]), "us_per_call": round(us, 1),
+                   "frac_algorithmic_of_8TBs": round(v["gbs"] / PEAK_HBM_GBS, 3), "traffic": None, "frac": None}
+            pe = pmc_abi.get(k)
+            if pe is not None:
+                tb = pe["traffic_bytes_per_launch"]
+                ent["traffic"] = round(tb)
+                ent["frac"] = round(tb / (us * 1e-6) / (PEAK_HBM_GBS * 1e9), 3)
+                if ent["frac"] > 0.79:
+                    ent["note"] = "above the 6.3 TB/s HBM delivers: part of these L2-side bytes were served by the Infinity Cache"
+            out["hbm_paths"][k] = ent
+        out["hbm_paths_note"] = ("gbs / frac_algorithmic_of_8TBs: algorithmic bytes over HIP-event time; traffic: PMC bytes per call "
+                                 "(rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes, profiles/pmc_latest.json; null when that file "
+                                 "is of other kernel sources / micro-batch); frac = traffic / time / 8 TB/s")
         out["kernel_breakdown"] = {k: {"ms": round(v["ms"], 3), "calls": v["calls"], "tflops": round(v["tflops"], 1),
                                         "gbs": round(v["gbs"], 1)} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     sd_cpu = None

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOM2P_HIP_LIB", os.path.join(_HERE, "libegom2p_hip.so"))   # override: kernel experiments
 MAX_MODS = 8
 
-ABI_VERSION = 5          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
+ABI_VERSION = 6          # == EGO_ABI_VERSION of include/egom2p_hip.h (tests/test_cabi_exports.py holds the two together)
 EPI_BF16, EPI_F32, EPI_RESID, EPI_BIAS_RESID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -23,7 +23,7 @@ class CompactDesc(C.Structure):
         ("mask", vp * MAX_MODS), ("ids", vp * MAX_MODS), ("dam", vp * MAX_MODS),
         ("n_pos", i32 * MAX_MODS), ("mod_id", i32 * MAX_MODS),
         ("ids_keep", vp), ("pad", vp), ("mod_mask", vp), ("slot", vp), ("local", vp), ("tok", vp),
-        ("ks", vp), ("ke", vp), ("n_valid", vp), ("seg", vp), ("err", vp), ("seg_bad", vp),
+        ("ks", vp), ("ke", vp), ("n_valid", vp), ("seg", vp), ("err", vp), ("seg_bad", vp), ("n_reg", i32),
     ]
 
 
@@ -42,7 +42,7 @@ class BudgetDesc(C.Structure):
 class EmbedDesc(C.Structure):
     _fields_ = [
         ("table", vp * MAX_MODS), ("pos", vp * MAX_MODS), ("mod", vp * MAX_MODS), ("base_vec", vp),
-        ("slot", vp), ("local", vp), ("tok", vp), ("x", vp), ("emb", vp), ("rows", i64), ("D", i32),
+        ("slot", vp), ("local", vp), ("tok", vp), ("x", vp), ("emb", vp), ("rows", i64), ("D", i32), ("reg", vp),
     ]
 
 
@@ -62,6 +62,7 @@ _SIGS = {
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
     "ego_embed_bwd_work_floats": [i64, i32, i32],
     "ego_embed_bwd": [C.POINTER(EmbedBwdDesc), vp],
+    "ego_reg_grad": [vp, i32, i64, i32, i32, vp, vp],
     "ego_rows_compact": [vp, i32, i32, vp, vp, vp],
     "ego_rows_gather": [vp, vp, vp, i32, i32, vp, vp],
     "ego_rows_scatter": [vp, vp, vp, i32, i32, vp, i32, vp],
@@ -110,7 +111,7 @@ _SIGS = {
     "ego_bias_grad": [vp, i64, i32, vp, vp, i64, vp],
     "ego_grad_sqnorm": [vp, i64, vp, vp, vp],
     "ego_adamw_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, i32, vp],
-    "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, f32, vp, vp, vp, i32, vp],
+    "ego_sample_cfg_topp": [vp, vp, i64, i32, f32, f32, i32, f32, vp, vp, vp, i32, vp],
     "ego_dp_unique_id": [vp],
     "ego_dp_comm_create": [vp, i32, i32, C.POINTER(vp)],
     "ego_dp_comm_destroy": [vp],

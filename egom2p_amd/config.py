@@ -56,6 +56,7 @@ class ModelCfg:
     modalities: Tuple[str, ...] = ("tok_rgb", "tok_depth", "tok_cam", "tok_gaze")
     share_embedding: bool = True       # decoder to_logits tied to decoder token_emb
     eps: float = 1e-6
+    num_register_tokens: int = 0       # learned [1, R, dim] rows in front of every sample's encoder tokens (egom2p_model.py:170-171, 381-387)
 
     @property
     def head_dim(self) -> int:
@@ -88,6 +89,8 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     "ego_tiny8_2e_2d": ModelCfg("ego_tiny8_2e_2d", 128, 2, 2, 2,
                                 modalities=("tok_cam", "tok_gaze") + tuple(f"tok_aux{i}" for i in range(6))),
     "ego_b_2e_2d": ModelCfg("ego_b_2e_2d", 768, 2, 2, 12),
+    # the same with four register tokens (`--num_register_tokens 4`, run_training_egom2p.py:70, 386): tests/golden/b2_reg4.npz
+    "ego_b_2e_2d_reg4": ModelCfg("ego_b_2e_2d_reg4", 768, 2, 2, 12, num_register_tokens=4),
     # untied decoder head (`share_embedding=False`, the FM wrapper's setting: egom2p_model.py:856-858) at parity-test depth
     "ego_b_2e_2d_untied": ModelCfg("ego_b_2e_2d_untied", 768, 2, 2, 12, share_embedding=False),
     "ego_L_1152": ModelCfg("ego_L_1152", 1152, 24, 24, 18),
@@ -99,6 +102,7 @@ MODEL_CFGS: Dict[str, ModelCfg] = {
     # rows of 2048, heads of 128, F padded to 5504 (the fused SwiGLU backward needs F % 256: this shape takes the two-call form)
     "ego_XL_2046_1e_1d": ModelCfg("ego_XL_2046_1e_1d", 2046, 1, 1, 31),
     "ego_gen_384_2e_2d": ModelCfg("ego_gen_384_2e_2d", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth")),
+    "ego_gen_384_2e_2d_reg4": ModelCfg("ego_gen_384_2e_2d_reg4", 384, 2, 2, 6, modalities=("tok_rgb", "tok_depth"), num_register_tokens=4),
     # config 4 (rgb -> depth generation) at ego-b width: D = 768, 12 heads of 64, F = 2048, at parity-test depth
     "ego_b_gen_2e_2d": ModelCfg("ego_b_gen_2e_2d", 768, 2, 2, 12, modalities=("tok_rgb", "tok_depth")),
 }

@@ -20,6 +20,7 @@ struct CompactArgs {
     int n_pos[EGO_MAX_MODS];
     int mod_id[EGO_MAX_MODS];
     int n_mods, T, n_keep, is_decoder;
+    int n_reg;                // register rows in front of every sample's kept rows (encoder only): outputs are [B, n_reg + n_keep]
     long long* ids_keep;      // [B, n_keep]
     unsigned char* pad;       // [B, n_keep]
     short* mod_mask;          // [B, n_keep]  (-1 on pads)
@@ -112,13 +113,27 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
     segstart[0] = 0;
 #pragma unroll
     for (int m = 0; m < EGO_MAX_MODS; ++m) segstart[m + 1] = segstart[m] + acc[5 + m];
+    const int pitch = a.n_reg + a.n_keep;           // entries per sample of every per-row output
     if (part == 0 && tid == 0) {
-        a.n_valid[b] = nv;
+        a.n_valid[b] = a.n_reg + nv;
         for (int m = 0; m < a.n_mods; ++m) {
             const int s0 = min(segstart[m], a.n_keep), s1 = min(segstart[m + 1], a.n_keep);
-            a.seg[((long)b * a.n_mods + m) * 2] = s0;
+            a.seg[((long)b * a.n_mods + m) * 2] = a.n_reg + s0;
             a.seg[((long)b * a.n_mods + m) * 2 + 1] = s1 - s0;
         }
+    }
+    if (part == 0 && tid < a.n_reg) {
+        // register rows (egom2p_model.py:381-387): never padding, no modality (mod_mask -1), slot -2 tells the embedding kernel
+        // to take row `local` of the register tokens; every key of the sample (registers included) is visible to them
+        const long o = (long)b * pitch + tid;
+        a.ids_keep[o] = -1;
+        a.pad[o] = 0;
+        a.mod_mask[o] = (short)-1;
+        a.slot[o] = -2;
+        a.local[o] = tid;
+        a.tok[o] = 0;
+        a.ks[o] = 0;
+        a.ke[o] = a.n_reg + nv;
     }
 
     // ---- pass 2: scatter this workgroup's run
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
             if (unm) { out = uidx; cs = run_du + w_du + du; }
             else { out = total_valid + (pos - uidx); cs = total_dam + run_dm + w_dm + dm; }
             if (out < a.n_keep) {
-                const long o = (long)b * a.n_keep + out;
+                const long o = (long)b * pitch + a.n_reg + out;
                 a.ids_keep[o] = pos;
                 a.pad[o] = masked ? 1 : 0;
                 a.mod_mask[o] = masked ? (short)-1 : (short)a.mod_id[m];
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactArgs a) {
                     if (unm && a.seg_bad && cs < s1) atomicOr(a.seg_bad + b, 1);
                 } else {
                     a.ks[o] = 0;
-                    a.ke[o] = nv;
+                    a.ke[o] = a.n_reg + nv;
                 }
             }
         }
@@ -189,6 +204,7 @@ struct EmbedArgs {
     const int* slot; const int* local; const int* tok;
     float* x; float* emb;               // [rows, D]; emb may be null
     long rows; int D;
+    const float* reg;                   // register tokens [n_reg, D] or null (rows with slot -2)
 };
 
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
@@ -200,8 +216,10 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     float* er = a.emb ? a.emb + row * a.D : nullptr;
     const int nc = a.D >> 2;
     if (s < 0) {
+        // padding row: zeros.  Register row (slot -2): x = register_tokens[local] + 0, emb = 0 (egom2p_model.py:384-385)
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < nc; c += 64) { *(f32x4*)(xr + c * 4) = z; if (er) *(f32x4*)(er + c * 4) = z; }
+        const float* rr = (s == -2 && a.reg) ? a.reg + (long)a.local[row] * a.D : nullptr;
+        for (int c = lane; c < nc; c += 64) { *(f32x4*)(xr + c * 4) = rr ? *(const f32x4*)(rr + c * 4) : z; if (er) *(f32x4*)(er + c * 4) = z; }
         return;
     }
     const float *tb = nullptr, *ps = nullptr, *md = nullptr;
@@ -672,8 +690,10 @@ extern "C" int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream)
         a.mod_id[m] = d->mod_id[m];
         T += d->n_pos[m];
     }
-    if (d->n_keep <= 0 || d->n_keep > T) return EGO_ERR_ARG;
-    a.n_mods = d->n_mods; a.T = T; a.n_keep = d->n_keep; a.is_decoder = d->is_decoder;
+    // register tokens: encoder side only, at most one workgroup's threads; with them a pass may keep no input row at all
+    if (d->n_reg < 0 || d->n_reg > 256 || (d->n_reg && d->is_decoder)) return EGO_ERR_ARG;
+    if (d->n_keep < (d->n_reg ? 0 : 1) || d->n_keep > T) return EGO_ERR_ARG;
+    a.n_mods = d->n_mods; a.T = T; a.n_keep = d->n_keep; a.is_decoder = d->is_decoder; a.n_reg = d->n_reg;
     a.ids_keep = (long long*)d->ids_keep; a.pad = (unsigned char*)d->pad; a.mod_mask = (short*)d->mod_mask;
     a.slot = d->slot; a.local = d->local; a.tok = d->tok; a.ks = d->ks; a.ke = d->ke;
     a.n_valid = d->n_valid; a.seg = d->seg; a.err = d->err; a.seg_bad = d->is_decoder ? d->seg_bad : nullptr;
@@ -688,8 +708,27 @@ extern "C" int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream) {
     EmbedArgs a{};
     for (int m = 0; m < EGO_MAX_MODS; ++m) { a.table[m] = d->table[m]; a.pos[m] = d->pos[m]; a.mod[m] = d->mod[m]; }
     a.base_vec = d->base_vec; a.slot = d->slot; a.local = d->local; a.tok = d->tok;
-    a.x = d->x; a.emb = d->emb; a.rows = d->rows; a.D = d->D;
+    a.x = d->x; a.emb = d->emb; a.rows = d->rows; a.D = d->D; a.reg = d->reg;
     EGO_LAUNCH(embed_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, stream, a);
+    LAUNCH_CHECK();
+    return EGO_OK;
+}
+
+namespace {
+// register-token gradient: dreg[r][c] += sum_b dx[(b * rps + r) * D + c], b ascending (one thread per (r, 4 columns))
+__global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__ dx, int B, long rps, int D, float* __restrict__ dreg) {
+    const int r = blockIdx.y, c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= D) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) acc += *(const f32x4*)(dx + ((long)b * rps + r) * D + c);
+    *(f32x4*)(dreg + (long)r * D + c) += acc;
+}
+}  // namespace
+
+extern "C" int ego_reg_grad(const float* dx, int B, long rows_per_sample, int n_reg, int D, float* dreg, hipStream_t stream) {
+    if (n_reg <= 0) return EGO_OK;
+    if (!dx || !dreg || B <= 0 || D <= 0 || D % 4 || n_reg > rows_per_sample || ((uintptr_t)dx | (uintptr_t)dreg) % 16) return EGO_ERR_ARG;
+    EGO_LAUNCH(reg_grad_kernel, dim3((unsigned)((D / 4 + 255) / 256), (unsigned)n_reg), dim3(256), 0, stream, dx, B, rows_per_sample, D, dreg);
     LAUNCH_CHECK();
     return EGO_OK;
 }

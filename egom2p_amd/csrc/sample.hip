@@ -2,7 +2,7 @@
 //
 // Replaces, per decoded row, the chain of the reference's GenerationSampler
 // (egom2p/models/generate.py): CFG mix `uncond + (cond - uncond) * s` (:805), nucleus filtering
-// `top_k_top_p_filtering` (:332-359, a full descending sort + cumsum + argsort + gather over V = 64000),
+// `top_k_top_p_filtering` (:332-359: top-k by torch.topk, then a full descending sort + cumsum + argsort + gather over V = 64000),
 // `softmax(filtered / temperature)` and `torch.multinomial` (:361-371).
 //
 // One 1024-thread workgroup per row.  The row (2 x 128 KB of bf16 logits at V = 64000) is read three times - the first
@@ -92,7 +92,7 @@ __device__ __forceinline__ void load_chunk(const bf16_t* __restrict__ c, const b
 
 template <bool VEC, bool CFG>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __restrict__ cond, const bf16_t* __restrict__ uncond,
-                                                             long ld, int V, float cfg, float top_p, float temperature,
+                                                             long ld, int V, float cfg, float top_p, int top_k, float temperature,
                                                              const float* __restrict__ uniforms, int* __restrict__ out_tok,
                                                              float* __restrict__ out_prob) {
     __shared__ float red[SMP_THREADS / 64];
@@ -135,8 +135,38 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
         return;
     }
 
-    // ---- pass 2: p = exp(mixed - max) (0 beyond V) and the nucleus cut: smallest bit pattern K with mass{p > K} <= top_p * Z
     float p[SMP_MAXE];
+    // ---- top-k (top_k_top_p_filtering, generate.py:335-345): remove every token whose mixed logit is below the k-th largest one
+    // (`logits < topk(logits, k)[0][..., -1]`: tokens that tie with the k-th stay).  The k-th largest is found without sorting by a
+    // 32-step binary search on the order-preserving integer key of the logit: the largest key T with count{key >= T} >= k; the
+    // registers that hold p afterwards hold the mixed logits during the search.  kth = 0 keeps everything.
+    unsigned kth = 0u;
+    if (top_k > 0 && top_k < V) {
+#pragma unroll
+        for (int m = 0; m < SMP_MAXE / 8; ++m) {
+            float v[8];
+            load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p[8 * m + e] = v[e];    // (a slot beyond V holds -3e38: below every real logit)
+        }
+        unsigned lo = 0u, hi = 0xffffffffu;                     // invariant: count{key >= lo} >= k
+        while (lo < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);     // upper middle: the loop ends at the LARGEST such key
+            float c0 = 0.f, c1 = 0.f;                           // counts <= 65536: exact in fp32
+#pragma unroll
+            for (int k = 0; k < SMP_MAXE; k += 2) {
+                c0 += (f2key(p[k]) >= mid) ? 1.f : 0.f;
+                c1 += (f2key(p[k + 1]) >= mid) ? 1.f : 0.f;
+            }
+            const float cnt = block_sum(c0 + c1, red);
+            if (cnt >= (float)top_k) lo = mid; else hi = mid - 1u;
+        }
+        kth = lo;
+    }
+
+    // ---- pass 2: p = exp(mixed - max) (0 beyond V and for tokens the top-k filter removed: the nucleus is taken over the
+    // renormalised survivors, as softmax of the filtered logits does) and the nucleus cut: smallest bit pattern K with
+    // mass{p > K} <= top_p * Z
     unsigned cut = 0u;                       // keep everything
     if (top_p > 0.f) {
         float z = 0.f;
@@ -146,7 +176,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
             load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                p[8 * m + e] = __expf(v[e] - mx);              // a slot beyond V: exp(-3e38 - max) = 0
+                p[8 * m + e] = f2key(v[e]) >= kth ? __expf(v[e] - mx) : 0.f;       // a slot beyond V: exp(-3e38 - max) = 0
                 z += p[8 * m + e];
             }
         }
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 8 * m + e;
-            const bool keep = cut == 0u || __float_as_uint(p[k]) >= cut;      // (a slot beyond V: q = exp(-inf) = 0 either way)
+            const bool keep = (cut == 0u || __float_as_uint(p[k]) >= cut) && f2key(v[e]) >= kth;   // (a slot beyond V: q = exp(-inf) = 0 either way)
             p[k] = keep ? __expf((v[e] - mx) * invT) : 0.f;
             mine += p[k];
         }
@@ -232,15 +262,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
 
 }  // namespace
 
-extern "C" int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, float cfg_scale, float top_p,
+extern "C" int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, float cfg_scale, float top_p, int top_k,
                                    float temperature, const float* uniforms, int* out_tokens, float* out_prob, int rows,
                                    hipStream_t stream) {
     if (rows <= 0) return EGO_OK;
-    if (V <= 0 || V > SMP_THREADS * SMP_MAXE || !cond || !uniforms || !out_tokens) return EGO_ERR_ARG;
+    if (V <= 0 || V > SMP_THREADS * SMP_MAXE || !cond || !uniforms || !out_tokens || top_k < 0) return EGO_ERR_ARG;
     const bool vec = V % 8 == 0 && V >= 8 && ld % 8 == 0 && ((((uintptr_t)cond) | ((uintptr_t)uncond)) & 15) == 0;
 #define SMP_GO(VEC, CFG)                                                                                                         \
     EGO_LAUNCH((sample_kernel<VEC, CFG>), dim3(rows), dim3(SMP_THREADS), 0, stream, (const bf16_t*)cond, (const bf16_t*)uncond, ld, V, \
-               cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob)
+               cfg_scale, top_p, top_k, temperature, uniforms, out_tokens, out_prob)
     if (vec && uncond) { SMP_GO(true, true); }
     else if (vec) { SMP_GO(true, false); }
     else if (uncond) { SMP_GO(false, true); }

@@ -118,6 +118,10 @@ class Engine:
         self.mods: List[Modality] = cfg.mods
         self.n_mods = len(self.mods)
         self.N, self.M, self.Bmax = n_enc, n_dec, max_batch
+        # register tokens (egom2p_model.py:170-171, 381-387): R learned rows in front of every sample's N kept encoder tokens - the
+        # encoder, the context and the cross-attention keys have Ne = R + N rows per sample; the compaction keeps N
+        self.R = int(getattr(cfg, "num_register_tokens", 0))
+        self.Ne = self.N + self.R
         self.scale = cfg.head_dim ** -0.5
         self._build_params()
         self._alloc_workspaces()
@@ -150,6 +154,11 @@ class Engine:
         # read once, one output per layer) and one backward (x once, one write of the context gradient) instead of one per layer
         self.ctx_ln_fused = (os.environ.get("EGOM2P_CTX_LN_FUSED", "1") != "0" and not self.fp8_forward and self.D <= 1536
                              and 0 < cfg.decoder_depth <= 32)
+
+    def layout_tag(self) -> Tuple[int, ...]:
+        """What the PHYSICAL flat buffers (P, G and the optimiser's m / v) depend on beyond the model: saved with optimiser
+        checkpoints and checked on load (a resume under another EGOM2P_HEAD_PAD must not die in a bare copy_)."""
+        return (2, int(self.n_flat), int(self.D), int(self.Hs), int(self.HDP), int(self.Fp))    # 2: context_norm weights in one group (round 5)
 
     def _ring_next(self):
         self._ring_i = (self._ring_i + 1) % len(self.ring_b)
@@ -191,7 +200,10 @@ class Engine:
             spec.append((name, tuple(shape)))
 
         def layer(prefix, kind):
-            norms = ["norm1", "norm2"] if kind == "enc" else ["norm1", "query_norm", "context_norm", "norm2"]
+            # (a decoder layer's context_norm weight lives in the "ctx_norms" group in front of the decoder layers: with the fused
+            #  context LayerNorm backward its gradient is only final after the LAST decoder layer's backward, and it must not
+            #  hold the layer's 14 MB gradient bucket back from the data-parallel exchange until then - ADVICE r4)
+            norms = ["norm1", "norm2"] if kind == "enc" else ["norm1", "query_norm", "norm2"]
             for n in norms:
                 add(f"{prefix}.{n}.weight", (D,))
             if kind == "enc":
@@ -214,6 +226,8 @@ class Engine:
         marks.append(("mod_emb", len(spec)))
         for m in self.mods:
             add(f"encoder_embeddings.{m.name}.mod_emb", (D,))
+        if getattr(cfg, "num_register_tokens", 0):
+            add("register_tokens", (cfg.num_register_tokens, D))       # reference shape (1, R, dim); decayed like mod_emb / mask_token
         for i in range(cfg.encoder_depth):
             marks.append((f"encoder.{i}", len(spec)))
             layer(f"encoder.{i}", "enc")
@@ -221,6 +235,10 @@ class Engine:
         add("encoder_norm.weight", (D,))
         add("decoder_proj_context.bias", (D,))
         add("decoder_proj_context.weight", (D, D))
+        if cfg.decoder_depth:
+            marks.append(("ctx_norms", len(spec)))
+            for i in range(cfg.decoder_depth):
+                add(f"decoder.{i}.context_norm.weight", (D,))
         for i in range(cfg.decoder_depth):
             marks.append((f"decoder.{i}", len(spec)))
             layer(f"decoder.{i}", "dec")
@@ -391,6 +409,8 @@ class Engine:
                 if name.endswith("norm.weight") or ".norm" in name or "norm1" in name or "norm2" in name:
                     out[name[:-len("weight")] + "bias"] = zeros
         out["mask_token"] = ref("mask_token").view(1, 1, D)
+        if self.R:
+            out["register_tokens"] = ref("register_tokens").view(1, self.R, D)
         return out
 
     def _canon_key(self, key: str) -> str:
@@ -412,7 +432,8 @@ class Engine:
         for store in (self.p, self.g):
             v = self._logical(ck, store[ck])
             if v.dim() <= 2:
-                shape = (1, 1, self.Dl) if (ck.endswith("mod_emb") or ck == "mask_token") else self._ref_shape(ck)
+                shape = ((1, 1, self.Dl) if (ck.endswith("mod_emb") or ck == "mask_token") else
+                         (1, self.R, self.Dl) if ck == "register_tokens" else self._ref_shape(ck))
                 v = v.view(shape)
             out.append(v)
         return out[0], out[1]
@@ -437,7 +458,7 @@ class Engine:
             if name in logit_keys:
                 a = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
                 v.copy_((torch.rand(v.shape, device=self.dev, generator=gen) * 2 - 1) * a)
-            elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token":
+            elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name in ("mask_token", "register_tokens"):
                 v.copy_(torch.randn(v.shape, device=self.dev, generator=gen) * 0.02)
             elif name.endswith("norm.weight") or ".norm" in name:
                 v.fill_(1.0)
@@ -471,7 +492,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------ workspaces
     def _alloc_workspaces(self):
-        B, N, M, D, A, Fp, H = self.Bmax, self.N, self.M, self.D, self.A, self.Fp, self.Hs
+        B, N, M, D, A, Fp, H = self.Bmax, self.Ne, self.M, self.D, self.A, self.Fp, self.Hs      # N: encoder rows per sample (registers included)
         dev, cfg = self.dev, self.cfg
         RN, RM = B * N, B * M
 
@@ -695,7 +716,7 @@ class Engine:
         self._loss_mode = ops.LOSS_MODES[loss_type]
         if self.weights_dirty:
             self.refresh_weights()
-        cfg, D, A, Fp, N, M = self.cfg, self.D, self.A, self.Fp, self.N, self.M
+        cfg, D, A, Fp, N, M = self.cfg, self.D, self.A, self.Fp, self.Ne, self.M      # N: encoder rows per sample (registers included)
         mods = self.mods
         B = mod_dict[mods[0].name]["input_mask"].shape[0]
         if B > self.Bmax:
@@ -713,14 +734,14 @@ class Engine:
         # ---- compaction + embeddings (egom2p_model.py:706-718, 723)
         ce, cd = self.ce, self.cd
         ops.compact([mod_dict[m.name]["input_mask"] for m in mods], [flat_ids(m) for m in mods], None,
-                    [m.max_tokens for m in mods], [m.id for m in mods], N, False, ce, B)
+                    [m.max_tokens for m in mods], [m.id for m in mods], self.N, False, ce, B, n_reg=self.R)
         ops.compact([mod_dict[m.name]["target_mask"] for m in dmods], [flat_ids(m) for m in dmods],
                     [mod_dict[m.name]["decoder_attention_mask"] for m in dmods],
                     [m.max_tokens for m in dmods], [m.id for m in dmods], M, True, cd, B)
         x0 = self.enc[0]["x"] if cfg.encoder_depth else self.x_enc_out
         ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
                       [self.pos[m.name] for m in mods], [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods],
-                      None, ce["slot"], ce["local"], ce["tok"], x0, self.emb_e, RN, D)
+                      None, ce["slot"], ce["local"], ce["tok"], x0, self.emb_e, RN, D, reg=self.p["register_tokens"] if self.R else None)
         y0 = self.dec[0]["x"] if cfg.decoder_depth else self.y_out
         ops.embed_fwd(None, [self.pos[m.name] for m in dmods], [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods],
                       self.p["mask_token"], cd["slot"], cd["local"], cd["tok"], y0, None, RM, D)
@@ -847,7 +868,7 @@ class Engine:
         `gscale` (float or 1-element device tensor: the upstream d loss).  `bucket_done(name, lo, hi)` is
         called (in launch order) as soon as every kernel writing G[lo:hi] has been enqueued."""
         assert self._have_fwd, "backward() needs a forward()"
-        cfg, D, A, N, M, B = self.cfg, self.D, self.A, self.N, self.M, self.B
+        cfg, D, A, N, M, B = self.cfg, self.D, self.A, self.Ne, self.M, self.B       # N: encoder rows per sample (registers included)
         RN, RM = B * N, B * M
         mods, ce, cd = self.mods, self.ce, self.cd
         if getattr(self, "_ce_done", None):
@@ -888,7 +909,6 @@ class Engine:
         fused = self.ctx_ln_fused
         if fused and self.dcn is None:
             self.dcn = [torch.empty(self.Bmax * N, D, device=self.dev, dtype=BF16) for _ in range(cfg.decoder_depth)]
-        held = []                     # decoder buckets whose context_norm weight gradient is still to come (fused backward)
         for i in reversed(range(cfg.decoder_depth)):
             w, pre = self.dec[i], f"decoder.{i}"
             dres_b = self._mlp_bwd(pre, w, dres, dres_b, RM, w["x2"])
@@ -909,22 +929,20 @@ class Engine:
                                   self.g[f"{pre}.context_norm.weight"], dx_in=None if first_ctx else self.dctx, width=self.Dl)
             first_ctx = False
             dres_b = self._self_attn_bwd(pre, "self_attn", w, dres, dres_b, RM, M, cd["ks"], cd["ke"], groups=self._dec_groups())
-            if fused:
-                held.append(pre)
-            else:
-                done(pre)
+            done(pre)                 # (the layer's context_norm weight is not in this bucket: "ctx_norms")
         if cfg.decoder_depth == 0:
             self.dctx[:RN].zero_()
         elif fused:
             # all layers' context_norm backward in one launch: the context and its statistics are read once, the context gradient
             # is written once (fp32 + the bf16 copy the context projection's backward reads) - summed in the chained launches'
-            # order, bit for bit their result; only now are the decoder layers' gradient buckets complete
+            # order, bit for bit their result; the layers' own gradient buckets went out layer by layer, only the small
+            # "ctx_norms" bucket (one weight vector per layer) is completed here
             Ld = cfg.decoder_depth
             ops.layernorm_bwd_multi([self.dcn[i][:RN] for i in range(Ld)], self.ctx[:RN], self.st_ctx[0], self.st_ctx[1],
                                     [self.p[f"decoder.{i}.context_norm.weight"] for i in range(Ld)], self.dctx[:RN],
                                     [self.g[f"decoder.{i}.context_norm.weight"] for i in range(Ld)], dx_bf16=self.dctx_b[:RN], width=self.Dl)
-            for pre in held:
-                done(pre)
+        if cfg.decoder_depth:
+            done("ctx_norms")
         # decoder input embeddings: mask token + (pos + mod_emb)
         dmods = self.dmods
         ops.embed_bwd(None, [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in dmods], self.g["mask_token"],
@@ -952,6 +970,8 @@ class Engine:
         ops.embed_bwd([self.g[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods],
                       [self.g[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, dxe, self.dctx,
                       ce["slot"], ce["tok"], RN, D, touched=getattr(self, "touched", None))
+        if self.R:        # d register_tokens = the encoder input gradient of the register rows, summed over the batch (emb is 0 there)
+            ops.reg_grad(dxe, B, N, self.R, D, self.g["register_tokens"])
         done("mod_emb")
         for m in reversed(mods):
             done(f"enc_table.{m.name}")
@@ -975,6 +995,7 @@ class Engine:
     def resize_workspaces(self, max_batch: int, n_enc: int, n_dec: int):
         """Re-allocate the activation workspaces for another (batch, N, M); parameters are untouched."""
         self.Bmax, self.N, self.M = max_batch, n_enc, n_dec
+        self.Ne = self.N + self.R
         self._alloc_workspaces()
         self._have_fwd = False
         self.drop_graphs()
@@ -1039,13 +1060,13 @@ class Engine:
         parts = [p for p in parts if p[2] > 0]
         R = sum(B * n for _, _, n, _ in parts)
         x, xn = w["xa"], w["xb"]
-        for side, enc_inputs, N, r0 in parts:
+        for side, enc_inputs, N, r0 in parts:          # N = rows per sample, the engine's register tokens included
             mods = [m for m in self.mods if m.name in enc_inputs]
             ops.compact([enc_inputs[m.name][1].contiguous() for m in mods], [enc_inputs[m.name][0].reshape(B, -1).contiguous() for m in mods],
-                        None, [m.max_tokens for m in mods], [m.id for m in mods], N, False, side, B)
+                        None, [m.max_tokens for m in mods], [m.id for m in mods], N - self.R, False, side, B, n_reg=self.R)
             ops.embed_fwd([self.p[f"encoder_embeddings.{m.name}.token_emb.weight"] for m in mods], [self.pos[m.name] for m in mods],
                           [self.p[f"encoder_embeddings.{m.name}.mod_emb"] for m in mods], None, side["slot"], side["local"], side["tok"],
-                          x[r0:], w["emb"][r0:], B * N, D)
+                          x[r0:], w["emb"][r0:], B * N, D, reg=self.p["register_tokens"] if self.R else None)
         for i in range(cfg.encoder_depth):
             pre = f"encoder.{i}"
             self._ln(x[:R], f"{pre}.norm1.weight", w["ln"], w["st"])
@@ -1131,7 +1152,7 @@ class Engine:
         if self.weights_dirty:
             self.refresh_weights()
         B, M = dec_pos.shape
-        N = int(n_enc)
+        N = int(n_enc) + self.R                  # register tokens ride in front of the kept inputs: the context is never empty then
         w = ws if ws is not None else self._alloc_infer(B, max(N, 1), M)
         side = w["sides"][0]
         if N > 0:
@@ -1154,6 +1175,7 @@ class Engine:
         Nc, Nu = int(n_cond), int(n_uncond)
         if Nc <= 0:
             raise ValueError("the conditional pass of a guided step has a context")
+        Nc, Nu = Nc + self.R, Nu + self.R        # register tokens ride in front of the kept inputs of either pass
         w = ws if ws is not None else self._alloc_infer(B, max(Nc, Nu, 1), M, groups=2)
         if w["groups"] < 2:
             raise ValueError("workspace allocated for single passes (groups=1)")
@@ -1198,7 +1220,7 @@ class Engine:
         V = {m.name: m for m in self.mods}[target].vocab_size
 
         def make_state():
-            return {"ws": self._alloc_infer(B, max(int(n_enc), 1), M, fresh=True),
+            return {"ws": self._alloc_infer(B, max(int(n_enc) + self.R, 1), M, fresh=True),
                     "ids": {n: enc_inputs[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names},
                     "mask": {n: enc_inputs[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names},
                     "pos": dec_pos.to(self.dev, I32).clone(),
@@ -1224,7 +1246,7 @@ class Engine:
         sets = (enc_cond, enc_uncond)
 
         def make_state():
-            return {"ws": self._alloc_infer(B, max(int(n_cond), int(n_uncond), 1), M, fresh=True, groups=2),
+            return {"ws": self._alloc_infer(B, max(int(n_cond), int(n_uncond), 1) + self.R, M, fresh=True, groups=2),
                     "ids": [{n: e[n][0].reshape(B, -1).to(self.dev, torch.int64).clone() for n in names} for e in sets],
                     "mask": [{n: e[n][1].reshape(B, -1).to(self.dev, torch.bool).clone() for n in names} for e in sets],
                     "pos": dec_pos.to(self.dev, I32).clone(),

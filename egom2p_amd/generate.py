@@ -157,8 +157,6 @@ class GenerationSampler:
                   static: Optional[dict] = None):
         """static (graph capture): {"noise", "n_dec", "n_enc_cond", "n_enc_uncond", "ws"} - every count comes from the
         schedule, every random number from a buffer filled before the replay: no host sync, no generator call."""
-        if top_k and top_k > 0:
-            raise NotImplementedError("top-k filtering is outside the hot-path scope (config 4 uses top-p)")
         eng = self.engine
         st = static or {}
         d = mod_dict[target_mod]
@@ -194,7 +192,8 @@ class GenerationSampler:
             uniforms = torch.rand(B * M, device=eng.dev)
         samples = torch.empty(B * M, device=eng.dev, dtype=torch.int32)
         ops.sample_cfg_topp(logits_cond.view(B * M, V), None if logits_uncond is None else logits_uncond.view(B * M, V), V,
-                            float(guidance_scale), float(top_p), float(temperature), uniforms, samples, ld=V)
+                            float(guidance_scale), float(top_p), float(temperature), uniforms, samples, ld=V,
+                            top_k=ops.top_k_count(top_k, V))          # int: a count, float: a share of V (generate.py:335-342)
         samples = samples.view(B, M).to(torch.int64)
         drawn = samples
         if forced_samples is not None:             # teacher forcing for parity tests: scatter the given tokens instead
@@ -230,8 +229,6 @@ class GenerationSampler:
         with torch's generator seeded `seed + step` exactly as the eager path does - same tokens, bit for bit.
         One graph per (batch, schedule, initial counts, top_p), kept in the engine's bounded graph cache."""
         eng = self.engine
-        if top_k and top_k > 0:
-            raise NotImplementedError("top-k filtering is outside the hot-path scope (config 4 uses top-p)")
         names = [m.name for m in eng.mods if m.name in mod_dict]
         B = mod_dict[names[0]]["tensor"].shape[0]
         flat = {n: {"tensor": mod_dict[n]["tensor"].reshape(B, -1).to(eng.dev, torch.int64),
@@ -255,7 +252,7 @@ class GenerationSampler:
             total_u = int(sum(n_in[n] + dec_so_far[n] for n in unc).max()) if unc else 0
             plan.append(dict(target=t, n_dec=n_dec, n_enc_cond=total, guided=guided, n_enc_uncond=total_u, info=info))
             dec_so_far[t] += n_dec
-        key = ("generate", bool(eng.cfg_pair), B, tuple(names), tuple((n, tuple(int(x) for x in n_in[n])) for n in names), tuple(sorted(n_open.items())), float(top_p),
+        key = ("generate", bool(eng.cfg_pair), B, tuple(names), tuple((n, tuple(int(x) for x in n_in[n])) for n in names), tuple(sorted(n_open.items())), float(top_p), (type(top_k).__name__, float(top_k or 0)),
                tuple((p["target"], p["n_dec"], p["info"]["temperature"], p["info"].get("cfg_scale", 1.0),
                       tuple(p["info"].get("cfg_cond_domains", []))) for p in plan))
         graphs = eng.__dict__.setdefault("_graphs", {})
@@ -265,7 +262,7 @@ class GenerationSampler:
                 graphs.pop(next(iter(graphs)))
             if eng.weights_dirty:
                 eng.refresh_weights()
-            n_max = max(max(p["n_enc_cond"] for p in plan), 1)
+            n_max = max(max(p["n_enc_cond"] for p in plan), 1) + getattr(eng, "R", 0)
             m_max = max(p["n_dec"] for p in plan)
             st = {"in": {n: {k: v.clone() for k, v in flat[n].items()} for n in names},
                   "noise": [torch.zeros(flat[p["target"]]["target_mask"].shape[1], device=eng.dev) for p in plan],
@@ -277,7 +274,7 @@ class GenerationSampler:
                 md = {n: {k: v.clone() for k, v in st["in"][n].items()} for n in names}
                 for i, p in enumerate(plan):
                     info = p["info"]
-                    md = self.roar_step(md, p["target"], p["n_dec"], info["temperature"], 0.0, top_p,
+                    md = self.roar_step(md, p["target"], p["n_dec"], info["temperature"], top_k, top_p,
                                         conditioning=info.get("cfg_cond_domains", []), guidance_scale=info.get("cfg_scale", 1.0),
                                         uniforms=st["uni"][i],
                                         static=dict(noise=st["noise"][i], n_dec=p["n_dec"], n_enc_cond=p["n_enc_cond"],

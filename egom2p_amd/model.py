@@ -140,7 +140,6 @@ class EgoM2P(nn.Module):
         if getattr(probe, "has_bias", True): unsupported.append("LayerNorm bias")
         if qk_norm: unsupported.append("qk_norm")
         if decoder_causal_mask or not decoder_sep_mask: unsupported.append("causal / non-separated decoder mask")
-        if num_register_tokens: unsupported.append("register tokens")
         if drop_path_rate_encoder or drop_path_rate_decoder: unsupported.append("drop path")
         if not share_modality_embeddings: unsupported.append("unshared modality embeddings")
         if set(encoder_embeddings) != set(decoder_embeddings): unsupported.append("different encoder/decoder modality sets")
@@ -149,8 +148,8 @@ class EgoM2P(nn.Module):
         self.modality_info = modality_info
         self.dim, self.init_std = dim, 0.02
         self.decoder_causal_mask, self.decoder_sep_mask = decoder_causal_mask, decoder_sep_mask
-        self.use_act_checkpoint, self.num_register_tokens = use_act_checkpoint, num_register_tokens
-        self.register_tokens = None
+        self.use_act_checkpoint, self.num_register_tokens = use_act_checkpoint, int(num_register_tokens)
+        # (register_tokens: nn.Parameter (1, R, dim) attached with the other views when R > 0 - egom2p_model.py:170-174)
         for emb in list(encoder_embeddings.values()) + list(decoder_embeddings.values()):
             emb.init(dim_tokens=dim, init_std=self.init_std)
         self.encoder_modalities, self.decoder_modalities = set(encoder_embeddings), set(decoder_embeddings)
@@ -167,7 +166,8 @@ class EgoM2P(nn.Module):
             mods.append(m)
         self._mods = mods
         self.cfg = ModelCfg("custom", dim, encoder_depth, decoder_depth, num_heads, mlp_ratio,
-                            modalities=tuple(m.name for m in mods), share_embedding=share, eps=probe.eps)
+                            modalities=tuple(m.name for m in mods), share_embedding=share, eps=probe.eps,
+                            num_register_tokens=int(num_register_tokens))
         # ModelCfg.mods looks names up in MODALITIES: custom vocab / positions go through a private table
         self._device = device or ("cuda:%d" % torch.cuda.current_device() if torch.cuda.is_available() else None)
         if self._device is None:
@@ -184,6 +184,8 @@ class EgoM2P(nn.Module):
         self._after_backward: Optional[Callable] = None
         self._sync_grads = True
         self._build_engine(1, 1, 1)
+        if not self.num_register_tokens:
+            self.register_tokens = None                 # the reference's attribute when there are none (:174)
         self.init_weights()
 
     # ---- engine + parameter views ---------------------------------------------------------------
@@ -264,8 +266,8 @@ class EgoM2P(nn.Module):
                 if dec_table and (tied or name.endswith("to_logits.weight")):
                     a = math.sqrt(6.0 / float(p.shape[0] + p.shape[1]))
                     p.uniform_(-a, a)
-                elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name == "mask_token":
-                    p.normal_(0, self.init_std)
+                elif name.endswith("token_emb.weight") or name.endswith("mod_emb") or name in ("mask_token", "register_tokens"):
+                    p.normal_(0, self.init_std)                     # (register_tokens: nn.init.normal_(std=init_std), :172)
                 elif "norm" in name and name.endswith(".weight") and p.dim() == 1:
                     p.fill_(1.0)
                 elif name.endswith(".bias"):

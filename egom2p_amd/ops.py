@@ -333,10 +333,11 @@ def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.95, eps=1e-8, gscale
                                   _p(sqnorm), int(zero_grad), _stream()), "ego_adamw_step")
 
 
-def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_pos, mod_ids, n_keep, is_decoder, out, B):
-    """`out`: dict of preallocated tensors (ids_keep,pad,mod_mask,slot,local,tok,ks,ke,n_valid,seg,err)."""
+def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_pos, mod_ids, n_keep, is_decoder, out, B, n_reg=0):
+    """`out`: dict of preallocated tensors (ids_keep,pad,mod_mask,slot,local,tok,ks,ke,n_valid,seg,err), n_reg + n_keep entries per
+    sample (n_reg: register tokens in front of the kept rows, encoder only)."""
     d = L.CompactDesc()
-    d.n_mods, d.n_keep, d.is_decoder = len(masks), n_keep, int(is_decoder)
+    d.n_mods, d.n_keep, d.is_decoder, d.n_reg = len(masks), n_keep, int(is_decoder), int(n_reg)
     for i in range(len(masks)):
         d.mask[i] = masks[i].data_ptr()
         d.ids[i] = ids[i].data_ptr()
@@ -349,8 +350,9 @@ def compact(masks: Sequence[torch.Tensor], ids: Sequence[torch.Tensor], dams, n_
     check(L.load().ego_compact(C.byref(d), B, _stream()), "ego_compact")
 
 
-def embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D):
+def embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D, reg=None):
     d = L.EmbedDesc()
+    d.reg = _p(reg)
     for i in range(len(pos)):
         d.table[i] = None if tables is None or tables[i] is None else tables[i].data_ptr()
         d.pos[i] = pos[i].data_ptr()
@@ -379,6 +381,10 @@ def embed_bwd(dtables, dmods, dbase, dx, d2, slot, tok, rows, D, touched=None):
     check(lib.ego_embed_bwd(C.byref(d), _stream()), "ego_embed_bwd")
 
 
+def reg_grad(dx, B, rows_per_sample, n_reg, D, dreg):
+    check(L.load().ego_reg_grad(_p(dx), B, rows_per_sample, n_reg, D, _p(dreg), _stream()), "ego_reg_grad")
+
+
 def rows_compact(touched, cap, rows, count):
     check(L.load().ego_rows_compact(_p(touched), touched.numel(), cap, _p(rows), _p(count), _stream()), "ego_rows_compact")
 
@@ -396,8 +402,22 @@ def loss_perm(seg, canon, slot, tok, B, M, n_mods, perm, tgt_perm, ranges, base)
                                  _p(base), _stream()), "ego_loss_perm")
 
 
-def sample_cfg_topp(cond, uncond, V, cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob=None, ld=None):
+def sample_cfg_topp(cond, uncond, V, cfg_scale, top_p, temperature, uniforms, out_tokens, out_prob=None, ld=None, top_k=0):
+    """top_k: number of tokens the top-k filter keeps (0 = off); `top_k_count` turns the reference's int / float argument into it"""
     rows = out_tokens.numel()
     ld = cond.stride(-2) if ld is None else ld
-    check(L.load().ego_sample_cfg_topp(_p(cond), _p(uncond), ld, V, cfg_scale, top_p, temperature, _p(uniforms), _p(out_tokens),
+    check(L.load().ego_sample_cfg_topp(_p(cond), _p(uncond), ld, V, cfg_scale, top_p, int(top_k), temperature, _p(uniforms), _p(out_tokens),
                                        _p(out_prob), rows, _stream()), "ego_sample_cfg_topp")
+
+
+def top_k_count(top_k, V: int) -> int:
+    """The k of `top_k_top_p_filtering` (egom2p/models/generate.py:335-342): an int is a count, a float a share of the vocabulary;
+    0 / 0.0 = no top-k filter.  k = 0 from a tiny positive share makes torch.topk(..., 0)[0][..., -1] raise in the reference."""
+    if not top_k or top_k <= 0:
+        return 0
+    if isinstance(top_k, bool) or not isinstance(top_k, (int, float)):
+        raise ValueError(f"Invalid value for top_k: {top_k}")
+    k = min(top_k, V) if isinstance(top_k, int) else min(int(top_k * V), V)
+    if k <= 0:
+        raise ValueError(f"top_k = {top_k} keeps no token of a {V}-token vocabulary")
+    return int(k)

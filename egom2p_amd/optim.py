@@ -42,8 +42,13 @@ class FusedAdamW:
             {"params": nodecay, "weight_decay": 0.0, "lr": lr, "lr_scale": 1.0, "name": "no_decay"},
         ]
         self._frozen_sig = None
-        self._runs = list(engine.opt_runs)
+        self._runs = [(lo, hi, nd, 0) for lo, hi, nd in engine.opt_runs]
         self._frozen_ranges: List = []          # [lo, hi) ranges of the flat buffers that belong to frozen tensors
+        self._frozen_names: List[str] = []
+        # torch.optim.AdamW keeps state["step"] PER PARAMETER and skips parameters without a gradient (requires_grad=False), so a
+        # tensor that is unfrozen after k steps (run_training_egom2p.py --frozen_model_epochs) starts its bias correction at 1,
+        # not at k + 1: `skipped[name]` = optimiser steps the tensor sat out; its effective step is t - skipped[name]
+        self.skipped: Dict[str, int] = {}
         self.last_grad_norm: Optional[torch.Tensor] = None
 
     def _active_runs(self):
@@ -53,27 +58,29 @@ class FusedAdamW:
         sig = tuple(p.requires_grad for _, p in self._named)
         if sig != self._frozen_sig:
             self._frozen_sig = sig
-            if all(sig):
-                self._runs = list(self.engine.opt_runs)
-                self._frozen_ranges = []
+            if all(sig) and not any(self.skipped.values()):
+                self._runs = [(lo, hi, nd, 0) for lo, hi, nd in self.engine.opt_runs]
+                self._frozen_ranges, self._frozen_names = [], []
             else:
-                eng, runs, fro = self.engine, [], []
+                eng, runs, fro, fnames = self.engine, [], [], []
                 frozen = {eng._canon_key(n) for (n, p) in self._named if not p.requires_grad} | set(eng.never_grad)
                 for name, (o, n, _) in eng.offsets.items():
                     n4 = (n + 3) // 4 * 4
                     if name in frozen:
+                        fnames.append(name)
                         if fro and fro[-1][1] == o:
                             fro[-1][1] = o + n4
                         else:
                             fro.append([o, o + n4])
                         continue
-                    nd = is_no_decay(name)
-                    if runs and runs[-1][2] == nd and runs[-1][1] == o:
+                    nd, sk = is_no_decay(name), self.skipped.get(name, 0)
+                    if runs and runs[-1][2] == nd and runs[-1][3] == sk and runs[-1][1] == o:
                         runs[-1][1] = o + n4
                     else:
-                        runs.append([o, o + n4, nd])
+                        runs.append([o, o + n4, nd, sk])
                 self._runs = [tuple(r) for r in runs]
                 self._frozen_ranges = [tuple(r) for r in fro]
+                self._frozen_names = [n for n in fnames if n not in eng.never_grad]
         return self._runs
 
     @torch.no_grad()
@@ -92,17 +99,19 @@ class FusedAdamW:
             if not self._frozen_ranges:
                 ops.grad_sqnorm(eng.G, self.sqnorm)
             else:
-                for lo, hi, _ in runs:
+                for lo, hi, _, _ in runs:
                     ops.grad_sqnorm(eng.G[lo:hi], self.sqnorm)
             norm = self.sqnorm.sqrt().to(torch.float32) * gscale
         if zero_grad:
             for lo, hi in self._frozen_ranges:      # never consumed: must not accumulate from step to step
                 eng.G[lo:hi].zero_()
         decay, nodecay = self.param_groups
-        for lo, hi, nd in runs:
+        for name in self._frozen_names:             # this step passes them by, as torch's per-parameter step counter would
+            self.skipped[name] = self.skipped.get(name, 0) + 1
+        for lo, hi, nd, sk in runs:
             grp = nodecay if nd else decay
             ops.adamw_step(eng.P[lo:hi], eng.G[lo:hi], self.m[lo:hi], self.v[lo:hi], float(grp["lr"]), float(grp["weight_decay"]),
-                           self.t, self.betas[0], self.betas[1], self.eps, gscale=gscale,
+                           self.t - sk, self.betas[0], self.betas[1], self.eps, gscale=gscale,
                            max_norm=float(clip_grad) if clip_grad else 0.0, sqnorm=self.sqnorm if clip_grad else None,
                            zero_grad=zero_grad)
         eng.weights_dirty = True
@@ -113,11 +122,22 @@ class FusedAdamW:
         self.engine.G.zero_()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t,
+        # m / v are the engine's PHYSICAL flat layout (padded heads, padded F): `layout` names it so that a resume under another
+        # layout (EGOM2P_HEAD_PAD, a round-3 ego-L checkpoint) fails with a message instead of a size mismatch or, worse, a fit
+        return {"m": self.m, "v": self.v, "t": self.t, "skipped": dict(self.skipped), "layout": self.engine.layout_tag(),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        have, want = sd.get("layout"), self.engine.layout_tag()
+        if have is not None and tuple(have) != tuple(want):
+            raise RuntimeError(f"optimizer state was saved for storage layout {tuple(have)}, this engine uses {tuple(want)} "
+                               "(layout version, n_flat, D, heads stored, head pitch, padded F): resume with the same EGOM2P_HEAD_PAD / model, "
+                               "or restart the optimizer state")
+        if sd["m"].numel() != self.m.numel():
+            raise RuntimeError(f"optimizer state has {sd['m'].numel()} moments, this engine {self.m.numel()} parameters")
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
+        self.skipped = {str(k): int(v) for k, v in sd.get("skipped", {}).items()}
+        self._frozen_sig = None                     # runs are rebuilt with the restored per-tensor step offsets
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 

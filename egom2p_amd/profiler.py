@@ -147,11 +147,11 @@ class KernelTimer:
         }
         # HBM-bound front-end / bookkeeping kernels: algorithmic bytes (the index streams once, only
         # the kept rows of the tables / positional tables, every output once)
-        def c_compact(masks, ids, dams, n_pos, mod_ids, n_keep, is_decoder, out, B):
+        def c_compact(masks, ids, dams, n_pos, mod_ids, n_keep, is_decoder, out, B, n_reg=0):
             T = sum(n_pos)
-            return 0.0, float(B) * (T * (1 + (4 if is_decoder else 0)) + n_keep * (8 + 31))
+            return 0.0, float(B) * (T * (1 + (4 if is_decoder else 0)) + (n_keep + n_reg) * (8 + 31))
 
-        def c_embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D):
+        def c_embed_fwd(tables, pos, mod, base_vec, slot, local, tok, x, emb, rows, D, reg=None):
             n_rw = (1 if tables is not None else 0) + 1 + 1 + (1 if emb is not None else 0)   # token row, pos row | x, emb
             return 0.0, float(rows) * D * 4 * n_rw + rows * 12.0
 

@@ -142,6 +142,8 @@ def build_state_dict(cfg: ModelCfg, seed: int = 0, posemb: bool = True) -> Dict[
         sd[f"{p}.mlp.fc3.weight"] = _xavier(f"{p}.mlp.fc3.weight", F, D, seed)
     _ln("decoder_norm", D, seed, sd)
     sd["mask_token"] = normal("mask_token", (1, 1, D), 0.02, seed)
+    if getattr(cfg, "num_register_tokens", 0):
+        sd["register_tokens"] = normal("register_tokens", (1, cfg.num_register_tokens, D), 0.02, seed)    # egom2p_model.py:170-172
     return sd
 
 

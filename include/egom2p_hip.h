@@ -24,8 +24,9 @@ extern "C" {
 /* bumped whenever an existing entry point changes its signature or meaning (2: round 2 added arguments to
  * ego_layernorm_fwd / ego_attn_*_d64 / ego_loss_finalize and removed ego_grad_scale; 3: round 3 gave ego_layernorm_bwd,
  * ego_bias_grad and ego_embed_bwd a scratch buffer for their atomic-free reductions; 4: ego_layernorm_fwd / _bwd take the
- * row pitch `ld` beside the normalised width D; 5: ego_compact_desc grew `seg_bad`, ego_embed_bwd_desc `vocab`, ego_ce_bwd / ego_ce_fwd_bwd / ego_loss_finalize take loss weights; loaders must refuse other versions) */
-#define EGO_ABI_VERSION 5
+ * row pitch `ld` beside the normalised width D; 5: ego_compact_desc grew `seg_bad`, ego_embed_bwd_desc `vocab`, ego_ce_bwd / ego_ce_fwd_bwd / ego_loss_finalize take loss weights; 6 (round 5): register tokens - ego_compact_desc grew `n_reg`,
+ * ego_embed_desc `reg`, new ego_reg_grad - and ego_sample_cfg_topp takes top_k; loaders must refuse other versions) */
+#define EGO_ABI_VERSION 6
 #define EGO_MAX_MODS 8
 
 /* GEMM epilogues */
@@ -69,6 +70,11 @@ typedef struct {
     int* seg_bad;                    /* out int32 [B] (decoder only, or NULL): nonzero if some kept unmasked row's interval
                                         is not exactly its slot's segment (start, count) - ego_attn_*_d64_seg then takes
                                         the per-row path for that sample                                                  */
+    int n_reg;                       /* register tokens (encoder only; egom2p_model.py:381-387): every per-row output has
+                                        n_reg + n_keep entries per sample, the first n_reg of them the register rows - pad 0,
+                                        mod_mask -1, slot -2, local = register index, tok 0, ids_keep -1 (the reference's
+                                        ids_keep has no such entries: compare [:, n_reg:]); n_valid and the key intervals
+                                        count them: n_valid = n_reg + kept, [ks, ke) = [0, n_valid)                         */
 } ego_compact_desc;
 int ego_compact(const ego_compact_desc* d, int B, hipStream_t stream);
 
@@ -84,6 +90,8 @@ typedef struct {
     const int* slot; const int* local; const int* tok;
     float* x; float* emb;
     long rows; int D;
+    const float* reg;                /* register tokens [n_reg, D] (egom2p_model.py:170-171) or NULL: a row with slot -2 is
+                                        x = reg[local], emb = 0 (`torch.cat([register_tokens, ...])`, zeros_like for emb)   */
 } ego_embed_desc;
 int ego_embed_fwd(const ego_embed_desc* d, hipStream_t stream);
 
@@ -103,6 +111,10 @@ typedef struct {
  * the table row's owner in ascending row order - results are bitwise reproducible.  Vocabularies up to 65536. */
 long ego_embed_bwd_work_floats(long rows, int D, int n_mods);
 int ego_embed_bwd(const ego_embed_bwd_desc* d, hipStream_t stream);
+/* Gradient of the register tokens (the backward of `repeat(self.register_tokens, '() n d -> b n d', b=B)`,
+ * egom2p_model.py:382): dreg[r] += sum over b (in batch order: bitwise reproducible) of dx[b * rows_per_sample + r], r < n_reg.
+ * (ego_embed_bwd skips rows with a negative slot, the register rows among them.) */
+int ego_reg_grad(const float* dx, int B, long rows_per_sample, int n_reg, int D, float* dreg, hipStream_t stream);
 
 /* Row lists for the sparse data-parallel exchange of an embedding table's gradient (replaces, for few clips per step,
  * the dense all-reduce DDP performs on the 64000 x 768 tables, run_training_egom2p.py:514; encoder_embeddings.py:200,291).
@@ -326,11 +338,13 @@ int ego_loss_finalize(const float* nll, const int* ranges, int n_mods, float* ou
 /* ---- generation (config 4) ------------------------------------------------------------------- */
 
 /* Per decoded row: logits = uncond + (cond - uncond) * cfg_scale (uncond NULL: logits = cond); nucleus
- * filter top_p (<= 0: off) on softmax(logits); sample from softmax(kept / temperature) with the caller's
- * uniform number uniforms[row] (temperature <= 1e-10: arg-max).  Replaces guided_roar_step_batched's CFG mix,
- * top_k_top_p_filtering, softmax and torch.multinomial (egom2p/models/generate.py:332-371, 805-808).
+ * top_k (> 0: keep the tokens whose logit is not below the k-th largest one - ties with it stay, generate.py:335-345; 0: off),
+ * then the nucleus filter top_p (<= 0: off) on the softmax of the surviving logits; sample from softmax(kept / temperature) with
+ * the caller's uniform number uniforms[row] (temperature <= 1e-10: arg-max).  Replaces guided_roar_step_batched's CFG mix,
+ * top_k_top_p_filtering, softmax and torch.multinomial (egom2p/models/generate.py:332-371, 805-808).  top_k is the COUNT
+ * (the reference turns a float top_k into int(top_k * V) on the host, :337-340).
  * cond/uncond: bf16 [rows, ld >= V]; out_prob (optional): probability of the sampled token. */
-int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, float cfg_scale, float top_p,
+int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld, int V, float cfg_scale, float top_p, int top_k,
                         float temperature, const float* uniforms, int* out_tokens, float* out_prob, int rows,
                         hipStream_t stream);
 

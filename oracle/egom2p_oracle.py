@@ -246,6 +246,13 @@ def forward(sd: Dict[str, torch.Tensor], cfg, mod_dict, n_enc: int, n_dec: int,
         e = f"encoder_embeddings.{m.name}"
         x_tok = x_tok.index_put((sel,), sd[f"{e}.token_emb.weight"][tok])
         x_emb = x_emb.index_put((sel,), sd[f"{e}.pos_emb"][0][loc] + sd[f"{e}.mod_emb"][0, 0])
+    R = int(getattr(cfg, "num_register_tokens", 0))
+    if R:                                                               # egom2p_model.py:381-387: register tokens in front, zero emb,
+        reg = sd["register_tokens"].expand(B, R, D)                     # never padding, modality id -1
+        x_tok = torch.cat([reg, x_tok], 1)
+        x_emb = torch.cat([torch.zeros(B, R, D), x_emb], 1)
+        pad_e = torch.cat([torch.zeros(B, R, dtype=torch.bool), pad_e], 1)
+        ce = dict(ce, pad=pad_e.numpy(), mod_mask=np.concatenate([np.full((B, R), -1, ce["mod_mask"].dtype), ce["mod_mask"]], 1))
     x = x_tok + x_emb                                                   # egom2p_model.py:718
     taps.update(enc_ids_keep=ce["ids_keep"], enc_pad=ce["pad"], enc_mod_mask=ce["mod_mask"], enc_x0=x)
 

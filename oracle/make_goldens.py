@@ -6,7 +6,7 @@ four hot-path files are loaded by file path under empty namespace stubs, as SURV
 describes.  Nothing from the reference is copied: this script *calls* its code and stores
 input-independent data (outputs on generator-made weights and clips) as fixtures.
 
-    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b12|L24|L1020|XL2046]
+    python oracle/make_goldens.py [--only tiny|tiny_pad|b2|b2_reg4|b12|L24|L1020|XL2046]
 
 Weights/clips come from `egom2p_amd.synth` (counter-based generator) so the GPU box can
 regenerate them bit-identically; fixtures hold integer outputs in full and float outputs as
@@ -75,7 +75,8 @@ def build_reference_model(cfg, enc, dec, model):
         encoder_embeddings=e_emb, decoder_embeddings=d_emb, modality_info=info,
         dim=cfg.dim, encoder_depth=cfg.encoder_depth, decoder_depth=cfg.decoder_depth,
         num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=False, proj_bias=False, mlp_bias=False,
-        norm_layer=partial(model.LayerNorm, eps=1e-6, bias=False), act_layer=torch.nn.SiLU, gated_mlp=True)
+        norm_layer=partial(model.LayerNorm, eps=1e-6, bias=False), act_layer=torch.nn.SiLU, gated_mlp=True,
+        num_register_tokens=getattr(cfg, "num_register_tokens", 0))
     return net
 
 
@@ -87,6 +88,7 @@ GRAD_TAPS_B = [
     "mask_token", "decoder_proj_context.bias", "decoder_proj_context.weight", "encoder_norm.weight",
     "decoder_norm.weight",
     "decoder_embeddings.tok_rgb.to_logits.weight", "decoder_embeddings.tok_gaze.to_logits.weight",   # untied head only
+    "register_tokens",                                                                                # num_register_tokens > 0 only
 ]
 
 
@@ -259,6 +261,11 @@ CASES = {
     # ego-b width, 2+2 layers, canonical split, N=M=2048
     "b2": dict(cfg_name="ego_b_2e_2d", batch=2, n_enc=2048, n_dec=2048, budgets=None, seed=3,
                full_float=False, py_seed=13),
+    # ego-b width, 2+2 layers, FOUR REGISTER TOKENS (egom2p_model.py:170-171, 381-387; `--num_register_tokens 4`): one clip at the
+    # canonical split, one with padding rows behind its inputs and targets (and no gaze input at all)
+    "b2_reg4": dict(cfg_name="ego_b_2e_2d_reg4", batch=2, n_enc=2048, n_dec=2048,
+                    budgets={"tok_rgb": [(1009, 1009), (700, 900)], "tok_depth": [(1009, 1009), (600, 800)],
+                             "tok_cam": [(15, 15), (10, 12)], "tok_gaze": [(15, 15), (0, 7)]}, seed=12, full_float=False, py_seed=22),
     # ego-b width, 2+2 layers, ragged budgets with padding
     "b2_ragged": dict(cfg_name="ego_b_2e_2d", batch=3, n_enc=2048, n_dec=2048, budgets="dirichlet", seed=4,
                       full_float=False, py_seed=14),

@@ -7,7 +7,7 @@ come from the counter-based generator.  Per schedule step the fixture holds the 
 statistics of the conditional / unconditional logits, and the tokens the reference sampled (teacher forcing
 for the next step).
 
-    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_b768 | gen_rgb2depth_b12 | gen_rgb2cam_b768 | gen_rgb2gaze_b768 | gen_depth2rgb_b768]
+    python oracle/make_goldens_generate.py [gen_rgb2depth | gen_rgb2depth_reg4 | gen_rgb2depth_b768 | gen_rgb2depth_b12 | gen_rgb2cam_b768 | gen_rgb2gaze_b768 | gen_depth2rgb_b768]
 """
 from __future__ import annotations
 
@@ -59,6 +59,8 @@ def main():
         # FULL-DEPTH config 4: the registered 12e/12d ego-b (400 M), rgb -> depth, N = 5120 / 6827 / 8534 encoder tokens on the
         # conditional passes and 0 / 1707 / 3414 on the unconditional ones (generate.py:785-817, 1031)
         "gen_rgb2depth_b12": ("egom2p_base_12e_12d_swiglu_nobias", 26, True, "tok_rgb", "tok_depth", 5120, 3),
+        # FOUR REGISTER TOKENS in front of the encoder tokens of every pass (generate.py:429-435) - see the note at `prompt_tokens` below
+        "gen_rgb2depth_reg4": ("ego_gen_384_2e_2d_reg4", 27, False, "tok_rgb", "tok_depth", 5120, 3),
     }
     cfg_name, seed, peaked, cond, target_mod, n_target, n_steps = TASKS[which]
     cfg = MODEL_CFGS[cfg_name]
@@ -71,6 +73,12 @@ def main():
     net.load_state_dict(sd, strict=True)
     net.eval()
     sampler = G.GenerationSampler(net)
+    if getattr(net, "num_register_tokens", 0) > 0:
+        # forward_mask_encoder_generation reads `self.prompt_tokens` (generate.py:430), an attribute GenerationSampler never sets:
+        # with num_register_tokens > 0 the reference's generation raises AttributeError as shipped.  The training path prepends
+        # `self.register_tokens` at the same place (egom2p_model.py:381-387) and the comment beside :430 says "prompt tokens at the
+        # beginning of the sequence": the fixture is made with the attribute pointing at the model's register tokens.
+        sampler.prompt_tokens = net.register_tokens
     info = net.modality_info
 
     # conditioning clip: the reference's own data file (real Cosmos ids of an rgb clip; for depth2rgb the same ids stand in

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import load_golden, rel_l2  # noqa: E402
+from conftest import bar, load_golden, rel_l2  # noqa: E402
 from egom2p_amd import _lib as L  # noqa: E402
 from egom2p_amd import ops, synth  # noqa: E402
 from egom2p_amd.config import MODEL_CFGS  # noqa: E402
@@ -59,10 +59,14 @@ def _tap(g, key, t):
 # of 1024 with 16 heads of 96 (15 padded heads + one all-zero phantom head: engine.py; "@128" = the round-3 layout, 15 heads of 128) -
 # the pad columns must stay exact zeros in activations and gradients
 # XL2046 = the registered ego-XL geometry (dim 2046, 31 heads of 66, F = 5456) at 1 + 1 layers, same storage scheme (32 heads of 96)
-@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b12", "L2", "L24", "L1020", "L1020@128", "XL2046"])
+# b2_reg4 = ego-b width with FOUR REGISTER TOKENS (egom2p_model.py:170-171, 381-387): R rows in front of every sample's encoder tokens
+@pytest.mark.parametrize("case", ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_untied", "b2_reg4", "b12", "L2", "L24", "L1020", "L1020@128", "XL2046"])
 def test_engine_matches_reference(case):
     g, meta, cfg, sd, md, eng = _setup(case)
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim
+    R = eng.R
+    assert R == cfg.num_register_tokens and eng.Ne == N + R
+    Ne = N + R                                           # encoder rows per sample: the reference's encoder_tokens.shape[1]
     Dp = eng.D                                           # row pitch of the engine's activations (== D unless stored padded)
 
     def act(t, rows, n):
@@ -74,7 +78,7 @@ def test_engine_matches_reference(case):
     torch.cuda.synchronize()
 
     # ---- integer / index outputs: bit-exact with the reference
-    assert np.array_equal(eng.ce["ids_keep"][:B].cpu().numpy(), g["enc_ids_keep"])
+    assert np.array_equal(eng.ce["ids_keep"][:B, R:].cpu().numpy(), g["enc_ids_keep"])    # (the reference's ids_keep has no register entries)
     assert np.array_equal(eng.cd["ids_keep"][:B].cpu().numpy(), g["dec_ids_keep"])
     assert np.array_equal(eng.ce["pad"][:B].cpu().numpy().astype(bool), g["enc_pad"])
     assert np.array_equal(eng.cd["pad"][:B].cpu().numpy().astype(bool), g["dec_pad"])
@@ -91,14 +95,16 @@ def test_engine_matches_reference(case):
     assert np.array_equal(allowed[~empty], ~blocked[~empty]) and blocked[empty].all()
 
     # ---- forward taps
-    RN, RM = B * N, B * M
-    enc0 = act(eng.enc[0]["x"], RN, N)
+    RN, RM = B * Ne, B * M
+    enc0 = act(eng.enc[0]["x"], RN, Ne)
     assert _tap(g, "enc_x0", enc0) < 1e-6                                     # exact fp32 gather + adds
+    if R:
+        assert torch.equal(enc0[:, :R].cpu(), sd["register_tokens"].expand(B, R, D))      # the register rows, bit for bit
     assert _tap(g, "dec_y0", act(eng.dec[0]["x"], RM, M)) < 1e-6
     blk0 = eng.enc[1]["x"] if cfg.encoder_depth > 1 else eng.x_enc_out
-    assert _tap(g, "enc_block0", act(blk0, RN, N)) < ACT_TOL
-    assert _tap(g, "enc_out", act(eng.xe, RN, N)) < ACT_TOL
-    assert _tap(g, "context", act(eng.ctx, RN, N)) < ACT_TOL
+    assert _tap(g, "enc_block0", act(blk0, RN, Ne)) < ACT_TOL
+    assert _tap(g, "enc_out", act(eng.xe, RN, Ne)) < ACT_TOL
+    assert _tap(g, "context", act(eng.ctx, RN, Ne)) < ACT_TOL
     dblk0 = eng.dec[1]["x"] if cfg.decoder_depth > 1 else eng.y_out
     # pad rows of the decoder stream are never consumed by the reference (mod_mask -1): compare valid rows
     valid = torch.from_numpy(~g["dec_pad"]).cuda()
@@ -155,7 +161,9 @@ def test_engine_matches_reference(case):
         # b12 / L2 / L24 (12+12 .. 24+24 layers of bf16 arithmetic against the fp32 reference), every one inside the near-tie
         # band above - their floor is 0.875 (8 of 64): a regression that flips a fifth of the rows inside the band fails.
         allowed = max(2, int((0.125 if m.vocab_size >= 4096 else 0.05) * rows))
-        assert int(mism.sum()) <= allowed, (m.name, int(mism.sum()), rows)
+        # ... and against the RECORDED count of this case and modality (tests/golden/parity_bars.json; b12 / L2 / L24 measured
+        # 4 / 5 / 6): at most two more flips than recorded - the engine drifting from 5 to 8 flips turns this red
+        bar(f"argmax_flips.{case}.{m.name}", int(mism.sum()), hard=allowed, rel_margin=0.0, abs_margin=2.0)
 
     # ---- backward + clip + AdamW
     eng.zero_grad()

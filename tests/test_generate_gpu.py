@@ -73,6 +73,53 @@ def test_sampler_kernel_nucleus_and_distribution():
     assert torch.equal(tok.long(), cond.float().argmax(-1)) and (prob == 1).all()
 
 
+def test_sampler_top_k_filter_matches_reference():
+    """top_k_top_p_filtering's top-k branch (egom2p/models/generate.py:335-345) in ego_sample_cfg_topp against the kept-token sets
+    of the REAL reference (tests/golden/topk_filter.npz, oracle/make_goldens_topk.py: int and float top_k, k >= V, k = 1, top-k
+    followed by top-p).  The kernel only returns samples, so each row is sampled S times at evenly spaced uniform numbers and
+    temperature 1e6 - every kept token then has the same mass, the set of sampled tokens IS the kept set and the reported
+    probability is 1 / |kept|.  Tokens that tie with the smallest kept logit are the reference's arbitrary choice (its
+    top-p sort) or kept together (its top-k `<`): the sets must agree outside those ties."""
+    import ast as _ast
+    g, _ = load_golden("topk_filter")
+    meta = _ast.literal_eval(str(g["meta"]))
+    rows, cfg_s = meta["rows"], meta["cfg_scale"]
+    assert ops.top_k_count(0.0, 64000) == 0 and ops.top_k_count(50, 64000) == 50 and ops.top_k_count(0.001, 64000) == 64
+    assert ops.top_k_count(300, 256) == 256
+    with pytest.raises(ValueError):
+        ops.top_k_count(1e-9, 64000)
+    for name, (V, top_k, top_p, scale) in meta["cases"].items():
+        c = synth.normal(f"topk.{name}.cond", (rows, V), scale, 0).bfloat16().to(DEV)
+        u = synth.normal(f"topk.{name}.uncond", (rows, V), scale, 0).bfloat16().to(DEV)
+        mixed = u.float() + (c.float() - u.float()) * cfg_s
+        k = ops.top_k_count(top_k, V)
+        S = 4096 if V <= 256 else 1024
+        uni = ((torch.arange(S, device=DEV, dtype=torch.float32) + 0.5) / S).contiguous()
+        for r in range(rows):
+            ref = g[f"kept.{name}"][r]
+            ref = set(int(x) for x in ref[ref >= 0])
+            lo = min(float(mixed[r, t]) for t in ref)
+            tied = set(int(x) for x in (mixed[r] == lo).nonzero()[:, 0].tolist())
+            tok = torch.empty(S, device=DEV, dtype=torch.int32)
+            prob = torch.empty(S, device=DEV)
+            ops.sample_cfg_topp(c[r:r + 1].expand(S, V).contiguous(), u[r:r + 1].expand(S, V).contiguous(), V, cfg_s, float(top_p), 1e6,
+                                uni, tok, prob, ld=V, top_k=k)
+            got = set(int(x) for x in tok.unique().tolist())
+            assert got - tied == ref - tied, (name, r, sorted(got ^ ref)[:8])
+            assert got <= ref | tied and len(got) >= len(ref - tied), (name, r)
+            n_kernel = round(1.0 / float(prob[0]))
+            assert n_kernel == len(got), (name, r, n_kernel, len(got))
+            if top_p == 0.0:                    # pure top-k: `logits < kth` keeps every tie, exactly the reference's set
+                assert got == ref, (name, r)
+        # top_k off reproduces the launch without the argument (same kernel path, kth = 0)
+        t0 = torch.empty(rows, device=DEV, dtype=torch.int32)
+        t1 = torch.empty(rows, device=DEV, dtype=torch.int32)
+        uu = torch.rand(rows, device=DEV)
+        ops.sample_cfg_topp(c, u, V, cfg_s, 0.8, 1.0, uu, t0, None, ld=V)
+        ops.sample_cfg_topp(c, u, V, cfg_s, 0.8, 1.0, uu, t1, None, ld=V, top_k=V)
+        assert torch.equal(t0, t1)
+
+
 def test_schedule_matches_reference():
     sch = build_chained_generation_schedules(["tok_rgb"], ["tok_depth"], [5120], ["roar"], [3], ["linear"], [0.01], ["constant"],
                                              [2.0], ["constant"], cfg_grow_conditioning=True)
@@ -81,7 +128,10 @@ def test_schedule_matches_reference():
     assert all(s["cfg_cond_domains"] == ["tok_rgb"] and s["cfg_scale"] == 2.0 and s["temperature"] == 0.01 for s in sch)
 
 
-@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_b768", "gen_rgb2depth_b12", "gen_rgb2cam_b768", "gen_rgb2gaze_b768", "gen_depth2rgb_b768"])
+# gen_rgb2depth_reg4: the D = 384 case with four register tokens in front of the encoder tokens of every pass - the unconditional
+# pass of step 0 then has a context of the 4 register rows instead of an empty one (generate.py:429-435; the fixture's note on
+# `prompt_tokens`: oracle/make_goldens_generate.py)
+@pytest.mark.parametrize("fixture", ["gen_rgb2depth", "gen_rgb2depth_reg4", "gen_rgb2depth_b768", "gen_rgb2depth_b12", "gen_rgb2cam_b768", "gen_rgb2gaze_b768", "gen_depth2rgb_b768"])
 def test_roar_cfg_generation_matches_reference(fixture):
     """gen_rgb2depth: D = 384 with a random-init (flat) head - near-ties decide most tokens, so the bars are on the logits.
     The *_b768 fixtures: ego-b width (D = 768, 12 heads) with a PEAKED target head (synth.peak_logit_table): arg-max and sampled

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 from egom2p_amd import _lib as L  # noqa: E402
 from egom2p_amd import ops  # noqa: E402
 
+from conftest import bar  # noqa: E402
+
 DEV = "cuda"
+ATT_FWD_TOL, ATT_BWD_TOL = 4e-3, 8e-3        # attention kernels against fp32 torch (relative L2), stated where they are used
 
 
 def _rel(a, b):
@@ -354,7 +357,11 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
     ops.attn_fwd(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o.data_ptr(), Nq * D, D, lse, ks, ke,
                  Nq, 1, B, H, Nq, Nk, scale)
     got = o.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
-    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    # stated tolerances: forward 4e-3, backward 8e-3 relative L2 against fp32 torch on the same bf16 inputs (bf16 output rounding
+    # alone is 2^-9 / sqrt(3) = 1.1e-3; the engine-level bf16-oracle test measures ~2e-3 / ~4e-3 through these kernels), and each
+    # value is also held to its recorded baseline + 30 % (conftest.bar)
+    tag = f"{B}x{H}x{Nq}x{Nk}.{kind}"
+    bar(f"attn_fwd.{tag}", _rel(got, ref), hard=ATT_FWD_TOL)
 
     do = _bf(torch.randn(B, Nq, D, device=DEV))
     ref.backward(do.view(B, Nq, H, 64).permute(0, 2, 1, 3).float())
@@ -367,9 +374,9 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, kind):
     gq = dq.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
     gk = dkv[:, :, 0].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
     gv = dkv[:, :, 1].reshape(B, Nk, H, 64).permute(0, 2, 1, 3).float()
-    assert _rel(gq, q.grad) < 2e-2, ("dq", _rel(gq, q.grad))
-    assert _rel(gk, k.grad) < 2e-2, ("dk", _rel(gk, k.grad))
-    assert _rel(gv, v.grad) < 2e-2, ("dv", _rel(gv, v.grad))
+    bar(f"attn_bwd_dq.{tag}", _rel(gq, q.grad), hard=ATT_BWD_TOL)
+    bar(f"attn_bwd_dk.{tag}", _rel(gk, k.grad), hard=ATT_BWD_TOL)
+    bar(f"attn_bwd_dv.{tag}", _rel(gv, v.grad), hard=ATT_BWD_TOL)
 
 
 @pytest.mark.parametrize("B,H,N,groups", [
@@ -439,11 +446,14 @@ def test_attention_row_groups(B, H, N, groups):
     o_r, lse_r, d_r = run()
     o_g, lse_g, d_g = run(seg=seg, seg_bad=bad)
     hv = lambda t: t.reshape(B, N, H, 64).permute(0, 2, 1, 3).float()
-    assert _rel(hv(o_g), ref) < 1e-2
-    assert _rel(hv(d_g[:, :, 0]), q.grad) < 2e-2 and _rel(hv(d_g[:, :, 1]), k.grad) < 2e-2 and _rel(hv(d_g[:, :, 2]), v.grad) < 2e-2
+    tag = f"{B}x{H}x{N}"
+    bar(f"attn_seg_fwd.{tag}", _rel(hv(o_g), ref), hard=ATT_FWD_TOL)
+    for i, (nm, gr) in enumerate((("dq", q.grad), ("dk", k.grad), ("dv", v.grad))):
+        bar(f"attn_seg_bwd_{nm}.{tag}", _rel(hv(d_g[:, :, i]), gr), hard=ATT_BWD_TOL)
     # against the per-row launches: the same arithmetic up to the order of the key tiles (online softmax / fp32 sums)
-    assert _rel(o_g.float(), o_r.float()) < 3e-3 and (lse_g - lse_r).abs().max().item() < 1e-3
-    assert _rel(d_g.float(), d_r.float()) < 5e-3
+    bar(f"attn_seg_vs_rows_o.{tag}", _rel(o_g.float(), o_r.float()), hard=3e-3)
+    assert (lse_g - lse_r).abs().max().item() < 1e-3
+    bar(f"attn_seg_vs_rows_d.{tag}", _rel(d_g.float(), d_r.float()), hard=5e-3)
     if int(bad.sum()):                       # the flagged sample takes the per-row path itself: bit for bit
         assert torch.equal(o_g[1], o_r[1]) and torch.equal(d_g[1], d_r[1])
     # every row written exactly (no 9.0 left), and two launches agree bit for bit
@@ -479,9 +489,12 @@ def test_attention_fwd_split_keys(B, H, Nq, Nk, splits):
     ops.attn_fwd_split(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o1.data_ptr(), Nq * D, D, lse1, ksb, keb, 1, 0,
                        B, H, Nq, Nk, scale, splits, ws)
     got = o1.view(B, Nq, H, 64).permute(0, 2, 1, 3).float()
-    assert _rel(got, ref) < 1e-2
-    # (both outputs are bf16 roundings of fp32 values that agree to ~1e-6: up to one bf16 ulp apart where a rounding boundary falls between them)
-    assert _rel(o1.float(), o0.float()) < 4e-3 and (lse1 - lse0).abs().max().item() < 1e-3
+    tag = f"{B}x{H}x{Nq}x{Nk}x{splits}"
+    bar(f"attn_split_fwd.{tag}", _rel(got, ref), hard=ATT_FWD_TOL)
+    # (both outputs are bf16 roundings of fp32 values that agree to ~1e-6: up to one bf16 ulp apart where a rounding boundary falls
+    #  between them; recorded 3.04e-3 on the (1, 12, 1707, 1707, 3) case - held to the recorded value + 15 %)
+    bar(f"attn_split_vs_unsplit.{tag}", _rel(o1.float(), o0.float()), hard=4e-3, rel_margin=0.15)
+    assert (lse1 - lse0).abs().max().item() < 1e-3
     with pytest.raises(L.EgoHipError):                       # scratch too small
         ops.attn_fwd_split(qb.data_ptr(), Nq * D, D, kp, Nk * 2 * D, 2 * D, vp, Nk * 2 * D, 2 * D, o1.data_ptr(), Nq * D, D, lse1, ksb, keb,
                            1, 0, B, H, Nq, Nk, scale, splits, ws[:-64])

@@ -155,6 +155,21 @@ def test_registry_and_scope_errors():
         logits = model({k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}, 256, 256, return_logits=True)
     assert logits["tok_rgb"].shape == (1, 256, 64000) and logits["tok_cam"].shape == (1, 256, 256)
     assert torch.isfinite(logits["tok_rgb"].float()).all()
+    # register tokens (`create_model(..., num_register_tokens=args.num_register_tokens)`, run_training_egom2p.py:381-387): a learned
+    # (1, R, dim) parameter under the reference's name, counted, trained (the engine-level parity is tests/golden/b2_reg4.npz)
+    assert model.register_tokens is None and "register_tokens" not in model.state_dict()
+    enc4 = {m: MODALITY_INFO[m]["encoder_embedding"]() for m in mods}
+    dec4 = {m: MODALITY_INFO[m]["decoder_embedding"]() for m in mods}
+    m4 = create_model("egom2p_tiny_6e_6d_swiglu_nobias", encoder_embeddings=enc4, decoder_embeddings=dec4,
+                      modality_info=MODALITY_INFO, num_register_tokens=4)
+    assert m4.num_register_tokens == 4 and tuple(m4.register_tokens.shape) == (1, 4, 384)
+    assert tuple(m4.state_dict()["register_tokens"].shape) == (1, 4, 384)
+    assert sum(p.numel() for p in m4.parameters()) == n + 4 * 384 == m4.engine.num_params()
+    assert abs(float(m4.register_tokens.detach().std()) - 0.02) < 4e-3            # nn.init.normal_(std=init_std), egom2p_model.py:172
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    loss, _ = m4(mdg, 256, 256)
+    loss.backward()
+    assert torch.isfinite(loss) and float(m4.register_tokens.grad.abs().sum()) > 0
 
 
 def _ego_b_2e_2d_model():
@@ -244,6 +259,63 @@ def test_frozen_encoder_steps_match_torch_adamw_on_the_unfrozen_subset():
         for n in frozen:
             assert torch.equal(named[n].detach(), frozen0[n]), n
         assert float(model.engine.G.abs().max().item()) == 0.0    # frozen ranges are cleared too
+
+
+def test_unfrozen_tensors_start_their_adamw_step_count_at_one():
+    """torch.optim.AdamW keeps state['step'] per parameter and passes parameters without a gradient by, so the
+    blocks that --frozen_model_epochs unfreezes after k steps get bias correction 1 - beta^1 on their first update, not
+    1 - beta^(k + 1) (with betas (0.9, 0.95) the latter makes the first dozens of updates ~0.45 x the reference's).  The SAME
+    torch optimiser sees requires_grad flip, exactly like the reference loop (run_training_egom2p.py:686-693); the optimiser
+    state also round-trips through state_dict() with the per-tensor offsets and the storage-layout tag."""
+    g, meta = load_golden("tiny")
+    cfg = MODEL_CFGS[meta["cfg"]]
+    sd = synth.build_state_dict(cfg, meta["seed"])
+    md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
+    mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
+    model = _tiny_model()
+    model.load_state_dict(sd)
+    args = types.SimpleNamespace(opt="adamw", lr=1e-2, weight_decay=0.05, opt_betas=(0.9, 0.95), opt_eps=1e-8)
+    opt = create_optimizer(args, model)
+    named = dict(model.named_parameters())
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in named.items()}
+    nd = lambda n: ("norm." in n or ".norm" in n or n.endswith(".bias"))
+    topt = torch.optim.AdamW([{"params": [ref[n] for n in named if not nd(n)], "weight_decay": 0.05},
+                              {"params": [ref[n] for n in named if nd(n)], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    shared = None
+    for step in range(5):
+        if step == 0:
+            model.freeze_shared_params()
+        elif step == 3:
+            model.unfreeze_all()
+        live = [n for n, p in named.items() if p.requires_grad]
+        if step == 0:
+            shared = [n for n in named if n not in live]
+            assert shared and live
+        random.seed(meta["py_seed"] + step)
+        loss, _ = model(mdg, meta["n_enc"], meta["n_dec"])
+        loss.backward()
+        for n in named:
+            ref[n].grad = named[n].grad.detach().clone() if n in live else None      # torch skips parameters without a gradient
+        before = {n: named[n].detach().clone() for n in shared}
+        topt.step()
+        opt.step(clip_grad=None)
+        for n in named:
+            assert rel_l2(named[n].detach().float().cpu().numpy(), ref[n].detach().float().cpu().numpy()) < 2e-6, (step, n)
+        if step == 3:
+            # first update of a just-unfrozen tensor: Adam's first step moves every element with a gradient by ~lr (bias
+            # correction 1 - beta^1); with the global counter (t = 4) it was ~0.45 lr for betas (0.9, 0.95)
+            n = next(x for x in shared if x.endswith("attn.qkv.weight"))
+            d = (named[n].detach() - before[n] * (1 - 1e-2 * 0.05)).abs()
+            assert float(d.max()) > 0.9e-2 and float(d.max()) < 1.01e-2, float(d.max())
+            assert topt.state[ref[n]]["step"].item() == 1 and opt.skipped[model.engine._canon_key(n)] == 3
+    # state round trip: a second optimiser restored from state_dict() takes the same next step; a foreign layout is refused
+    st = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in opt.state_dict().items()}
+    opt2 = create_optimizer(args, model)
+    opt2.load_state_dict(st)
+    assert opt2.t == opt.t and opt2.skipped == opt.skipped and [r[3] for r in opt2._active_runs()] == [r[3] for r in opt._active_runs()]
+    bad = dict(st, layout=(1, 2, 3, 4, 5))
+    with pytest.raises(RuntimeError, match="storage layout"):
+        create_optimizer(args, model).load_state_dict(bad)
 
 
 def test_training_script_resumes_where_it_stopped(tmp_path):

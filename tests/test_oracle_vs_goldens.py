@@ -18,7 +18,7 @@ from oracle import egom2p_oracle as O
 
 FP32_TOL = 2e-5
 
-CASES = ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "L1020"]
+CASES = ["tiny", "tiny_pad", "tiny8", "b2", "b2_ragged", "b2_reg4", "L1020"]
 if os.environ.get("EGOM2P_SLOW") == "1":
     CASES += ["b12", "L2", "L24", "XL2046"]
 

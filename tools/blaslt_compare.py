@@ -36,16 +36,22 @@ def main():
     torch.manual_seed(0)
     shapes = [("qkv", 2304, 768), ("kv", 1536, 768), ("proj/q", 768, 768), ("fc13", 4096, 768), ("fc2", 768, 2048),
               ("dgrad qkv", 768, 2304), ("dgrad fc13", 768, 4096), ("dgrad fc2", 2048, 768), ("logits", 64000, 768), ("dgrad logits", 768, 64000)]
+    only = [x.strip() for x in os.environ.get("SHAPES", "").split(",") if x.strip()]      # e.g. SHAPES="fc2,dgrad qkv,dgrad fc13"
+    lib_only = os.environ.get("LIB_ONLY") == "1"          # under rocprofv3 --kernel-trace: the library's kernels only (tools/blaslt_names.sh)
     for name, N, K in shapes:
+        if only and name not in only:
+            continue
         m = M if "logits" not in name else 64576
         x = torch.randn(m, K, device=dev).bfloat16()
         w = torch.randn(N, K, device=dev).bfloat16()
         y = torch.empty(m, N, device=dev, dtype=torch.bfloat16)
         t_lib = timeit(lambda: F.linear(x, w))
-        t_own = timeit(lambda: ops.gemm_nt(x, w, y, m, N, K, L.EPI_BF16))
+        t_own = t_lib if lib_only else timeit(lambda: ops.gemm_nt(x, w, y, m, N, K, L.EPI_BF16))
         fl = 2.0 * m * N * K
         print(f"NT {name:13s} M={m} N={N} K={K}: library {t_lib:8.1f} us = {fl / t_lib / 1e6:7.1f} TF/s   own {t_own:8.1f} us = {fl / t_own / 1e6:7.1f} TF/s", flush=True)
         del x, w, y
+    if only or lib_only:
+        return
     # weight gradients: dW[N, K] = dY[M, N]^T X[M, K]
     for name, N, K in [("wgrad qkv", 2304, 768), ("wgrad fc13", 4096, 768), ("wgrad fc2", 768, 2048), ("wgrad proj", 768, 768)]:
         dy = torch.randn(M, N, device=dev).bfloat16()

@@ -18,7 +18,14 @@ from egom2p_amd.profiler import kernel_source_sha  # noqa: E402
 
 CLASSES = [("gemm_nt256", r"gemm_nt256_kernel"), ("gemm_nt", r"gemm_nt_kernel"), ("gemm_tn256", r"gemm_tn256_kernel"),
            ("gemm_tn", r"gemm_tn_kernel"), ("attn_fwd", r"attn_fwd_kernel"), ("attn_bwd_dq", r"attn_bwd_dq_kernel"),
-           ("attn_bwd_dkv", r"attn_bwd_dkv_kernel"), ("ln_bwd", r"ln_bwd_kernel"), ("ln_fwd", r"ln_fwd_kernel")]
+           ("attn_bwd_dkv", r"attn_bwd_dkv_kernel"), ("ln_bwd", r"ln_bwd_kernel"), ("ln_fwd", r"ln_fwd_kernel"),
+           # round 5: the HBM-bound paths north_star names - front end, loss, fused norms, optimiser
+           ("ln_fwd_multi", r"ln_fwd_multi_kernel"), ("ln_bwd_multi", r"ln_bwd_multi_kernel"), ("colsum", r"colsum_kernel"),
+           ("ce_fwd_bwd", r"ce_fwd_bwd_kernel"), ("embed", r"::embed_kernel"), ("compact", r"compact_kernel"),
+           ("embed_tables", r"embed_tables_kernel"), ("embed_sums", r"embed_sums_kernel"), ("adamw", r"adamw_kernel"),
+           ("cast_w", r"cast_w_kernel"), ("sqnorm", r"sqnorm_kernel"), ("tn_reduce", r"tn_reduce_kernel"),
+           ("bias_grad", r"bias_grad_kernel"), ("loss_perm", r"loss_perm_kernel"), ("swiglu_fwd", r"swiglu_fwd_kernel"),
+           ("swiglu_bwd", r"swiglu_bwd_kernel")]
 
 
 def load(path, counter):
@@ -47,16 +54,27 @@ def main():
                     "traffic_bytes_per_launch": 2.0 * f_kb * 1024 / n + w_kb * 1024 / max(n2, 1)}
     # C-ABI level classes (what bench.py's KernelTimer brackets): both device kernels of one entry point together
     abi = {}
+    # (the first listed kernel gives the call count of a multi-kernel entry point; gemm_nt / gemm_tn: either kernel is a call.
+    #  The HBM-bound entries carry bench.py's hbm_paths names; colsum_kernel's bytes are shared by the LayerNorm / embedding
+    #  backward launches and stay a class of their own: ~0.3 % of ln_bwd's bytes)
     for entry, parts in (("gemm_nt", ("gemm_nt", "gemm_nt256")), ("gemm_tn", ("gemm_tn", "gemm_tn256")),
-                         ("attn_bwd", ("attn_bwd_dq", "attn_bwd_dkv")), ("attn_fwd", ("attn_fwd",))):
+                         ("attn_bwd", ("attn_bwd_dq", "attn_bwd_dkv")), ("attn_fwd", ("attn_fwd",)),
+                         ("layernorm_fwd", ("ln_fwd",)), ("layernorm_bwd", ("ln_bwd",)), ("layernorm_fwd_multi", ("ln_fwd_multi",)),
+                         ("layernorm_bwd_multi", ("ln_bwd_multi",)), ("ce_fwd_bwd", ("ce_fwd_bwd",)), ("other:embed_fwd", ("embed",)),
+                         ("other:compact", ("compact",)), ("other:embed_bwd", ("embed_sums", "embed_tables")),
+                         ("other:adamw_step", ("adamw",)), ("other:cast_weight", ("cast_w",)), ("other:grad_sqnorm", ("sqnorm",)),
+                         ("other:bias_grad", ("bias_grad",)), ("other:loss_perm", ("loss_perm",))):
         have = [out[k] for k in parts if k in out]
         if not have:
             continue
-        n = sum(h["launches"] for h in have) if entry != "attn_bwd" else have[0]["launches"]
+        n = sum(h["launches"] for h in have) if entry in ("gemm_nt", "gemm_tn") else have[0]["launches"]
         tot = sum(h["traffic_bytes_per_launch"] * h["launches"] for h in have)
         abi[entry] = {"launches": n, "traffic_bytes_per_launch": tot / n}
     meta = {"note": "HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE doubled "
-                    "per the gfx950 correction (MI355X_MICROARCH.md, HBM); counter units KiB -> bytes",
+                    "per the gfx950 correction (MI355X_MICROARCH.md, HBM); counter units KiB -> bytes.  The correction is calibrated for "
+                    "wide (16 B per lane) streaming reads, which is what the row kernels issue; FETCH_SIZE counts requests leaving the "
+                    "L2s, Infinity-Cache hits included: bytes a 256 MB cache serves (weights, a tensor the previous kernel just wrote) "
+                    "are in `traffic` but never reached HBM",
             "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --clips-per-gpu MB --micro-batch MB --steps 1 "
                        "--warmup 0 --no-cpu-baseline --no-kernel-profile",
             "micro_batch": int(os.environ.get("EGOM2P_PMC_MICRO_BATCH", "64")), "kernel_src_sha": kernel_source_sha(), "kernels": out, "abi": abi}
