@@ -195,8 +195,9 @@ def extra_config5(device, clips=64, mb=32, steps=2):
     f_fwd = flops_per_clip(cfg, synth.CANONICAL_BUDGETS, 2048, 2048)
     out = {"workload": f"ego_L_1152 (1.19 B) training step, {clips} clips, micro-batch {mb}, canonical 10300-position clips",
            "algorithmic_tflop_per_clip": round(3 * f_fwd / 1e12, 3)}
-    for tag, fp8 in (("bf16", False), ("fp8", True)):
-        eng = Engine(cfg, device, max_batch=mb, n_enc=2048, n_dec=2048, fp8_forward=fp8)
+    # "fp8": forward linears on e4m3; "fp8_bwd": forward AND dgrad GEMMs on e4m3 (weight gradients bf16) - DESIGN section 4f
+    for tag, fp8, fp8b in (("bf16", False, False), ("fp8", True, False), ("fp8_bwd", True, True)):
+        eng = Engine(cfg, device, max_batch=mb, n_enc=2048, n_dec=2048, fp8_forward=fp8, fp8_backward=fp8b)
         eng.init_random(seed=0)
         mbs = [synth.make_clip_batch_device(cfg, mb, synth.CANONICAL_BUDGETS, seed=100, sample_offset=i * mb, device=device) for i in range(2)]
         step = TrainStep(eng, lr=1e-4, weight_decay=0.05, clip_grad=1.0)
@@ -274,6 +275,7 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--fp8", action="store_true", help="forward linears on e4m3 operands (BASELINE config 5: bf16 + fp8 MFMA GEMMs)")
+    ap.add_argument("--fp8-bwd", action="store_true", help="with --fp8: the dgrad GEMMs on e4m3 operands too (weight gradients stay bf16)")
     ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default=None,
                     help="gradient exchange per bucket: RCCL all-reduce (ring) or in-place reduce-scatter + all-gather (default: $EGOM2P_DP_ALGO or allreduce)")
     ap.add_argument("--dp-backend", choices=["torch", "cabi"], default="torch",
@@ -337,7 +339,7 @@ def main():
     mb = min(args.micro_batch, args.clips_per_gpu)
     n_mb = args.clips_per_gpu // mb
     clips = n_mb * mb
-    eng = Engine(cfg, dev, max_batch=mb, n_enc=n_enc, n_dec=n_dec, fp8_forward=args.fp8)
+    eng = Engine(cfg, dev, max_batch=mb, n_enc=n_enc, n_dec=n_dec, fp8_forward=args.fp8, fp8_backward=args.fp8 and args.fp8_bwd)
     eng.init_random(seed=0)                      # same weights on every rank (DDP broadcast semantics)
     budgets = synth.CANONICAL_BUDGETS
     pool = 2                                     # distinct micro-batches per rank, cycled (inputs stay in HBM)
@@ -393,7 +395,7 @@ def main():
                    f"multimodal tokens/sec ({args.model}, 10300-tok clips), training fwd+bwd+allreduce+AdamW"),
         "value": value, "unit": "clip-positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16+fp8fwd" if args.fp8 else "bf16", "data": "synthetic",
+        "dtype": ("bf16+fp8fwd+fp8dgrad" if args.fp8_bwd else "bf16+fp8fwd") if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} mod4, synthetic 10300-position clips (1009+1009 rgb, 1009+1009 depth, 15+15 cam, "
                                f"15+15 gaze kept -> N=M=2048), bf16 MFMA GEMM/attention, fp32 residual/LN/CE/AdamW",
                    "clips_per_gpu_per_step": clips, "micro_batch": mb, "global_batch": clips * world, **par},

@@ -38,6 +38,7 @@ struct NTArgs {
     const bf16_t* X; long ldx;      // EPI_SWIGLU_BWD: the saved SwiGLU pre-activations ab [M, 2N]
     bf16_t* H; long ldh;            // EPI_SWIGLU_FWD: the gate output h [M, N]
     const float* sa; const float* sb;   // fp8 operands: per-row scales of A [M] and of B [N rows] (C = sa[m] * sb[n] * acc)
+    int dephase;                        // timing probe (ego_gemm_tune key 1): every other workgroup of an XCD starts this many ~0.5 us late
 };
 constexpr int EPI_SWIGLU_FWD = 101;   // internal: C = ab [M, 2N] and H = bf16(bf16(silu(a)) * b) [M, N] from one 256 x (128 a + 128 b) tile
 constexpr int EPI_SWIGLU_BWD = 100;   // internal: C(bf16)[M, 2N] = SwiGLU backward of (acc rounded to bf16) against X
@@ -424,6 +425,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     if ((int)blockIdx.x >= ntiles) return;
     const int nt = p.K * ESZ / 128;                            // K-tiles of 128 bytes
     const int G = gridDim.x;
+    // De-phasing probe: all persistent workgroups start together and run equal tiles, so
+    // their epilogue store bursts hit HBM at the same moments; with p.dephase > 0 every other workgroup of an XCD starts late.
+    // 0 (the product setting) compiles to one scalar compare; results are identical either way.
+    if (p.dephase > 0 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(16);          // 16 x 64 clocks ~ 0.5 us at 2 GHz
 
     // A: one descriptor per 256-row tile (based at the tile's first row, sized to its valid rows), so the 32-bit buffer
     // offsets never see more than 256 rows - activations / logit gradients larger than 4 GiB are fine
@@ -1254,6 +1260,7 @@ constexpr long TN256_MIN_AREA = 512L * 1024L;     // smallest Ni*Nj sent to the 
 int g_nt256 = 1;
 int g_tn256 = 1;
 int g_nt64_tiles = 400;      // NT launches of at most this many 128x128 tiles run on 64x64 tiles instead (0 = never; ego_gemm_small_tiles)
+int g_nt_dephase = 0;        // timing probe of the persistent 256 x 256 NT kernel (ego_gemm_tune key 1); 0 = product behaviour
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
@@ -1297,6 +1304,15 @@ extern "C" int ego_gemm_small_tiles(int max_tiles128) {
     return old;
 }
 
+extern "C" int ego_gemm_tune(int key, int value) {
+    // probe hook (no reference counterpart; results never change): key 1 = start delay, in units of ~0.5 us, of every other
+    // persistent 256 x 256 NT workgroup of an XCD.  Returns the previous value, value < 0 only queries.
+    if (key != 1) return -1;
+    const int old = g_nt_dephase;
+    if (value >= 0) g_nt_dephase = value;
+    return old;
+}
+
 extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                                 const float* R, long ldr, const float* bias, const int* m_range,
                                 int M, int N, int K, int epi, hipStream_t stream) {
@@ -1306,7 +1322,7 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
     if ((epi == EGO_EPI_RESID || epi == EGO_EPI_BIAS_RESID) && (!R || ldr % 4)) return EGO_ERR_ARG;
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     ensure_attrs();
-    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0, nullptr, 0, nullptr, nullptr};
+    NTArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, R, ldr, bias, m_range, M, N, K, epi, nullptr, 0, nullptr, 0, nullptr, nullptr, g_nt_dephase};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     // The persistent 256x256 kernel runs one workgroup per CU.  Measured on MI355X (tools/gemm_bench.py, EGO_GEMM_NT256=2
     // forces it): it wins when the tiles fill the 256 CUs for about three rounds or more, and for deep K already from a
@@ -1344,7 +1360,7 @@ extern "C" int ego_gemm_nt_swiglu_fwd(const void* X, long ldx, const void* W13, 
     if (256L * ldx * 2 >= 0x7ff00000L || 2L * F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)X, ldx, (const bf16_t*)W13, ldw, ab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_FWD,
-             nullptr, 0, (bf16_t*)h, ld_h, nullptr, nullptr};
+             nullptr, 0, (bf16_t*)h, ld_h, nullptr, nullptr, g_nt_dephase};
     const int tiles = ((M + 255) / 256) * (F / 128);
     EGO_LAUNCH(gemm_nt256_kernel<3>, dim3(tiles < 256 ? tiles : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();
@@ -1362,7 +1378,7 @@ extern "C" int ego_gemm_nt_fp8(const void* A8, long lda, const float* sa, const 
     if (epi == EGO_EPI_BIAS_RESID && !bias) return EGO_ERR_ARG;
     if (256L * lda >= 0x7ff00000L || (long)N * ldb >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
-    NTArgs a{(const bf16_t*)A8, lda, (const bf16_t*)B8, ldb, C, ldc, R, ldr, bias, nullptr, M, N, K, epi, nullptr, 0, nullptr, 0, sa, sb};
+    NTArgs a{(const bf16_t*)A8, lda, (const bf16_t*)B8, ldb, C, ldc, R, ldr, bias, nullptr, M, N, K, epi, nullptr, 0, nullptr, 0, sa, sb, g_nt_dephase};
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     if (epi == EGO_EPI_BF16) { EGO_LAUNCH((gemm_nt256_kernel<0, true>), dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
     else { EGO_LAUNCH((gemm_nt256_kernel<1, true>), dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
@@ -1377,7 +1393,7 @@ extern "C" int ego_gemm_nt_swiglu_fwd_fp8(const void* X8, long ldx, const float*
     if (256L * ldx >= 0x7ff00000L || 2L * F * ldw >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)X8, ldx, (const bf16_t*)W13_8, ldw, ab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_FWD,
-             nullptr, 0, (bf16_t*)h, ld_h, sx, sw};
+             nullptr, 0, (bf16_t*)h, ld_h, sx, sw, g_nt_dephase};
     const int tiles = ((M + 255) / 256) * (F / 128);
     EGO_LAUNCH((gemm_nt256_kernel<3, true>), dim3(tiles < 256 ? tiles : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();
@@ -1392,7 +1408,7 @@ extern "C" int ego_gemm_nt_swiglu_bwd(const void* dY, long ldy, const void* W2t,
     if (256L * ldy * 2 >= 0x7ff00000L || (long)F * ldw * 2 >= 0xfff00000L) return EGO_ERR_ARG;
     ensure_attrs();
     NTArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)W2t, ldw, dab, ld_ab, nullptr, 0, nullptr, nullptr, M, F, K, EPI_SWIGLU_BWD,
-             (const bf16_t*)ab, ld_ab, nullptr, 0, nullptr, nullptr};
+             (const bf16_t*)ab, ld_ab, nullptr, 0, nullptr, nullptr, g_nt_dephase};
     const int tiles256 = ((M + 255) / 256) * (F / 256);
     EGO_LAUNCH(gemm_nt256_kernel<2>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a);
     LAUNCH_CHECK();

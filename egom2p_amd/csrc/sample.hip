@@ -90,7 +90,9 @@ __device__ __forceinline__ void load_chunk(const bf16_t* __restrict__ c, const b
     }
 }
 
-template <bool VEC, bool CFG>
+// TOPK: its own instantiations - the search loop and its compares cost the top-p-only kernel (config 4) 100 spilled registers
+// when they share one (0.49 -> 1.22 ms per 1707-row launch, rocprofv3 profiles/r05_eval_rgb2depth_kernel_stats.csv history)
+template <bool VEC, bool CFG, bool TOPK>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __restrict__ cond, const bf16_t* __restrict__ uncond,
                                                              long ld, int V, float cfg, float top_p, int top_k, float temperature,
                                                              const float* __restrict__ uniforms, int* __restrict__ out_tok,
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
     // 32-step binary search on the order-preserving integer key of the logit: the largest key T with count{key >= T} >= k; the
     // registers that hold p afterwards hold the mixed logits during the search.  kth = 0 keeps everything.
     unsigned kth = 0u;
-    if (top_k > 0 && top_k < V) {
+    if constexpr (TOPK) {
 #pragma unroll
         for (int m = 0; m < SMP_MAXE / 8; ++m) {
             float v[8];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
             load_chunk<VEC, CFG>(c, u, V, cfg, tid, m, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                p[8 * m + e] = f2key(v[e]) >= kth ? __expf(v[e] - mx) : 0.f;       // a slot beyond V: exp(-3e38 - max) = 0
+                p[8 * m + e] = (!TOPK || f2key(v[e]) >= kth) ? __expf(v[e] - mx) : 0.f;       // a slot beyond V: exp(-3e38 - max) = 0
                 z += p[8 * m + e];
             }
         }
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const bf16_t* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 8 * m + e;
-            const bool keep = (cut == 0u || __float_as_uint(p[k]) >= cut) && f2key(v[e]) >= kth;   // (a slot beyond V: q = exp(-inf) = 0 either way)
+            const bool keep = (cut == 0u || __float_as_uint(p[k]) >= cut) && (!TOPK || f2key(v[e]) >= kth);   // (a slot beyond V: q = exp(-inf) = 0 either way)
             p[k] = keep ? __expf((v[e] - mx) * invT) : 0.f;
             mine += p[k];
         }
@@ -268,13 +270,16 @@ extern "C" int ego_sample_cfg_topp(const void* cond, const void* uncond, long ld
     if (rows <= 0) return EGO_OK;
     if (V <= 0 || V > SMP_THREADS * SMP_MAXE || !cond || !uniforms || !out_tokens || top_k < 0) return EGO_ERR_ARG;
     const bool vec = V % 8 == 0 && V >= 8 && ld % 8 == 0 && ((((uintptr_t)cond) | ((uintptr_t)uncond)) & 15) == 0;
-#define SMP_GO(VEC, CFG)                                                                                                         \
-    EGO_LAUNCH((sample_kernel<VEC, CFG>), dim3(rows), dim3(SMP_THREADS), 0, stream, (const bf16_t*)cond, (const bf16_t*)uncond, ld, V, \
+    const bool topk = top_k > 0 && top_k < V;            // k >= V removes nothing
+#define SMP_GO(VEC, CFG, TOPK)                                                                                                   \
+    EGO_LAUNCH((sample_kernel<VEC, CFG, TOPK>), dim3(rows), dim3(SMP_THREADS), 0, stream, (const bf16_t*)cond, (const bf16_t*)uncond, ld, V, \
                cfg_scale, top_p, top_k, temperature, uniforms, out_tokens, out_prob)
-    if (vec && uncond) { SMP_GO(true, true); }
-    else if (vec) { SMP_GO(true, false); }
-    else if (uncond) { SMP_GO(false, true); }
-    else { SMP_GO(false, false); }
+#define SMP_GO2(VEC, CFG) do { if (topk) { SMP_GO(VEC, CFG, true); } else { SMP_GO(VEC, CFG, false); } } while (0)
+    if (vec && uncond) SMP_GO2(true, true);
+    else if (vec) SMP_GO2(true, false);
+    else if (uncond) SMP_GO2(false, true);
+    else SMP_GO2(false, false);
+#undef SMP_GO2
 #undef SMP_GO
     LAUNCH_CHECK();
     return EGO_OK;

@@ -72,9 +72,9 @@ def _pad128(n: int) -> int:
 class _Lin:
     """One linear layer: master view [out, in] (possibly padded), bf16 W [out, in] and W^T [in, out]; with the fp8
     forward enabled also W as OCP e4m3 bytes with one fp32 scale per output channel."""
-    __slots__ = ("name", "w", "g", "wb", "wt", "out_f", "in_f", "w8", "s8")
+    __slots__ = ("name", "w", "g", "wb", "wt", "out_f", "in_f", "w8", "s8", "wt8", "st8")
 
-    def __init__(self, name, w, g, dev, fp8=False):
+    def __init__(self, name, w, g, dev, fp8=False, fp8_bwd=False):
         self.name, self.w, self.g = name, w, g
         self.out_f, self.in_f = w.shape
         self.wb = torch.zeros(self.out_f, self.in_f, device=dev, dtype=BF16)
@@ -82,11 +82,15 @@ class _Lin:
         ok8 = fp8 and self.in_f % 128 == 0 and self.in_f >= 256 and self.out_f % 128 == 0
         self.w8 = torch.zeros(self.out_f, self.in_f, device=dev, dtype=torch.uint8) if ok8 else None
         self.s8 = torch.ones(self.out_f, device=dev, dtype=F32) if ok8 else None
+        # fp8 dgrad (dX = dY W): W^T [in, out] as e4m3 with one scale per input channel - the contraction runs over `out`
+        okb = fp8_bwd and self.out_f % 128 == 0 and self.out_f >= 256 and self.in_f % 128 == 0
+        self.wt8 = torch.zeros(self.in_f, self.out_f, device=dev, dtype=torch.uint8) if okb else None
+        self.st8 = torch.ones(self.in_f, device=dev, dtype=F32) if okb else None
 
 
 class Engine:
     def __init__(self, cfg: ModelCfg, device="cuda:0", max_batch: int = 1, n_enc: int = 2048, n_dec: int = 2048,
-                 attn_o_residual: str = "cross", fp8_forward: bool = False):
+                 attn_o_residual: str = "cross", fp8_forward: bool = False, fp8_backward: bool = False):
         """attn_o_residual: which attention sites also keep the bf16 rounding residual of their output so that the
         backward's delta = rowsum(dO o O) is formed from O to ~16 bits ("cross": the cross-attention sites - where, with
         near-uniform attention over ~2000 context keys, the plain flash-style delta put 3.5 % error on the query-path
@@ -96,6 +100,12 @@ class Engine:
         # context projection) run on e4m3 operands - activations quantised per row right before the GEMM, weights per
         # output channel once per optimiser step - with fp32 accumulation; the backward and the logits stay bf16.
         self.fp8_forward = bool(fp8_forward)
+        # fp8_backward (round 5): the dgrad GEMMs dX = dY W on e4m3 operands too - dY quantised per row (the
+        # contraction runs over the output channels, so a per-row scale of dY and a per-input-channel scale of W^T factor out
+        # exactly like the forward's scales); e4m3 rather than e5m2 because the per-ROW scale already takes the gradient's
+        # row-to-row dynamic range out and the 3-bit mantissa is then the limit.  Weight gradients stay bf16: their contraction
+        # runs over the rows, where per-row scales do not factor out.  Measured gain / kill criterion: DESIGN section 4f.
+        self.fp8_backward = bool(fp8_backward)
         if attn_o_residual not in ("cross", "all", "none"):
             raise ValueError("attn_o_residual must be 'cross', 'all' or 'none'")
         self.attn_o_residual = attn_o_residual
@@ -112,8 +122,8 @@ class Engine:
         self.HDP, self.Hs = head_layout(cfg.num_heads, cfg.head_dim, int(os.environ.get("EGOM2P_HEAD_PAD", "0")))
         self.A = self.Hs * self.HDP
         self.padded = self.D != self.Dl or self.HDP != self.HD or self.Hs != self.H
-        if self.padded and fp8_forward:
-            raise L.EgoHipError("the fp8 forward is built for the unpadded shapes (dim % 128 == 0, head_dim 64)")
+        if self.padded and (fp8_forward or fp8_backward):
+            raise L.EgoHipError("the fp8 GEMMs are built for the unpadded shapes (dim % 128 == 0, head_dim 64)")
         self.F, self.Fp = cfg.mlp_hidden, _pad128(cfg.mlp_hidden)
         self.mods: List[Modality] = cfg.mods
         self.n_mods = len(self.mods)
@@ -296,7 +306,8 @@ class Engine:
         self.lin: Dict[str, _Lin] = {}
 
         def lin(name):
-            self.lin[name] = _Lin(name, self.p[name], self.g[name], self.dev, fp8=self.fp8_forward and "token_emb" not in name and "to_logits" not in name)
+            body = "token_emb" not in name and "to_logits" not in name
+            self.lin[name] = _Lin(name, self.p[name], self.g[name], self.dev, fp8=self.fp8_forward and body, fp8_bwd=self.fp8_backward and body)
 
         for i in range(cfg.encoder_depth):
             for s in ("attn.qkv", "attn.proj", "mlp.fc2"):
@@ -320,7 +331,7 @@ class Engine:
         n = 2 * self.Fp * self.D
         w = self.P[o1:o1 + n].view(2 * self.Fp, self.D)
         g = self.G[o1:o1 + n].view(2 * self.Fp, self.D)
-        self.lin[f"{prefix}.mlp.fc13"] = _Lin(f"{prefix}.mlp.fc13", w, g, self.dev, fp8=self.fp8_forward)
+        self.lin[f"{prefix}.mlp.fc13"] = _Lin(f"{prefix}.mlp.fc13", w, g, self.dev, fp8=self.fp8_forward, fp8_bwd=self.fp8_backward)
 
     # reference key layout <-> engine storage ----------------------------------------------------
     def _view_for_key(self, key: str) -> Optional[torch.Tensor]:
@@ -488,6 +499,8 @@ class Engine:
             ops.cast_weight(l.w, l.wb, l.wt)
             if l.w8 is not None:
                 ops.quant_fp8_rows(l.wb, l.w8, l.s8)
+            if l.wt8 is not None:
+                ops.quant_fp8_rows(l.wt, l.wt8, l.st8)
         self.weights_dirty = False
 
     # ------------------------------------------------------------------------------------ workspaces
@@ -569,8 +582,8 @@ class Engine:
         self.dyn = torch.zeros(RM, D, device=dev, dtype=BF16)
         self.delta = e(B, H, max(N, M), dt=F32)
         self.slab = e(64 * 1024 * 1024 // 4, dt=F32)   # 64 MiB of split-K partials (256 workgroups x 256 KiB)
-        if self.fp8_forward:                           # e4m3 copy + row scales of the current GEMM input
-            self.q8 = e(R, max(D, Fp), dt=torch.uint8)
+        if self.fp8_forward or self.fp8_backward:      # e4m3 copy + row scales of the current GEMM input
+            self.q8 = e(R, max(D, 3 * A, 2 * Fp), dt=torch.uint8)
             self.qs = e(R, dt=F32)
         self.gscale = torch.ones(1, device=dev, dtype=F32)
 
@@ -587,8 +600,8 @@ class Engine:
             ops.layernorm_fwd(x, self.p[wname], y, st[0], st[1], out_row=out_row, eps=self.cfg.eps, width=self.Dl)
 
     def _qbuf(self, rows, K):
-        if getattr(self, "q8", None) is None or self.q8.shape[0] < rows:
-            self.q8 = torch.empty(rows, max(self.D, self.Fp), device=self.dev, dtype=torch.uint8)
+        if getattr(self, "q8", None) is None or self.q8.shape[0] < rows or self.q8.shape[1] < K:
+            self.q8 = torch.empty(rows, max(self.D, 3 * self.A, 2 * self.Fp), device=self.dev, dtype=torch.uint8)
             self.qs = torch.empty(rows, device=self.dev, dtype=F32)
         self._q_of = None
         return self.q8[:, :K]
@@ -627,7 +640,10 @@ class Engine:
     def _lin_bwd(self, name, dY, X, dX, rows):
         """dX(bf16) = dY @ W ; dW += dY^T @ X."""
         l = self.lin[name]
-        if dX is not None:
+        if dX is not None and l.wt8 is not None and rows > 0:
+            q = self._quant(dY, rows, l.out_f)               # e4m3 rows of dY + per-row scales (one pass over dY)
+            ops.gemm_nt_fp8(q, self.qs, l.wt8, l.st8, dX, rows, l.in_f, l.out_f, L.EPI_BF16)
+        elif dX is not None:
             ops.gemm_nt(dY, l.wt, dX, rows, l.in_f, l.out_f, L.EPI_BF16, lda=dY.shape[-1], ldb=l.out_f, ldc=dX.shape[-1])
         self._wgrad(l.g, dY, X, l.out_f, l.in_f, rows, ldp=dY.shape[-1], ldq=X.shape[-1])
 

@@ -43,6 +43,10 @@ int ego_gemm_kernel_mode(int nt256, int tn256);
  * path, egom2p/models/generate.py:747-766) run on the 64x64-tile small-grid kernel; 0 = never, < 0 = query only.  Returns
  * the previous threshold (default 400).  Same results (same K order); test / tuning hook like ego_gemm_kernel_mode. */
 int ego_gemm_small_tiles(int max_tiles128);
+/* Probe hook (timing only, results never change; no reference counterpart).  key 1: every other persistent 256 x 256 NT workgroup
+ * of an XCD starts `value` x ~0.5 us late (de-phases the workgroups' epilogue store bursts: tools/dephase_probe.py); 0 = off (the
+ * product setting).  Returns the previous value; value < 0 only queries; unknown key: -1. */
+int ego_gemm_tune(int key, int value);
 
 /* ---- front end ------------------------------------------------------------------------------- */
 

@@ -350,19 +350,24 @@ def test_micro_batch_64_equals_two_accumulated_halves():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("bwd", [False, True], ids=["fwd", "fwd+dgrad"])
 @pytest.mark.parametrize("case", ["b2", "L2"])
-def test_fp8_forward_stays_within_stated_tolerance(case):
+def test_fp8_forward_stays_within_stated_tolerance(case, bwd):
     """BASELINE config 5 ("bf16 + fp8 MFMA GEMMs"): the forward linears on e4m3 operands (per-row activation scales,
     per-output-channel weight scales, fp32 accumulation), backward in bf16.  The reference has no fp8 path: the bar is
     a stated tolerance against its fp32 outputs (tests/golden/{b2,L2}.npz) - loss within 1e-2 relative, activation
     taps within 1e-1 (e4m3 keeps 3 mantissa bits: 4-9e-2 measured), every per-tensor gradient norm within 1e-1, total
-    gradient norm within 3e-2 - next to the bf16 engine's 1e-3 / 2e-2 / 4e-2 / 1e-2 on the same fixtures."""
+    gradient norm within 3e-2 - next to the bf16 engine's 1e-3 / 2e-2 / 4e-2 / 1e-2 on the same fixtures.
+    "fwd+dgrad" (round 5): the dgrad GEMMs dX = dY W on e4m3 too (`fp8_backward`: dY quantised per row, W^T per input channel;
+    weight gradients stay bf16) - the same bars on the loss and the taps (the forward is the same), per-tensor gradient norms
+    within 1.5e-1 and the total within 5e-2 (every gradient now passes through up to 2 x depth e4m3 roundings)."""
     g, meta = load_golden(case)
     cfg = MODEL_CFGS[meta["cfg"]]
     sd = synth.build_state_dict(cfg, meta["seed"])
     md = synth.make_clip_batch(cfg, meta["batch"], meta["budgets"], meta["seed"])
-    eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"], fp8_forward=True)
+    eng = Engine(cfg, "cuda:0", max_batch=meta["batch"], n_enc=meta["n_enc"], n_dec=meta["n_dec"], fp8_forward=True, fp8_backward=bwd)
     assert all(l.w8 is not None for n, l in eng.lin.items() if "embeddings" not in n)
+    assert all((l.wt8 is not None) == bwd for n, l in eng.lin.items() if "embeddings" not in n)
     eng.load_state_dict(sd)
     mdg = {k: {kk: vv.cuda() for kk, vv in v.items()} for k, v in md.items()}
     B, N, M, D = meta["batch"], meta["n_enc"], meta["n_dec"], cfg.dim
@@ -390,8 +395,10 @@ def test_fp8_forward_stays_within_stated_tolerance(case):
             worst = (n, e)
     total = sum(eng.grad_of(n).double().pow(2).sum().item() for n in names) ** 0.5
     print(case, "fp8 worst grad-norm error", worst, "total", abs(total - float(g["grad_total_norm"])) / float(g["grad_total_norm"]))
-    assert worst[1] < 1e-1, worst
-    assert abs(total - float(g["grad_total_norm"])) < 3e-2 * float(g["grad_total_norm"])
+    tag = f"fp8{'_dgrad' if bwd else ''}.{case}"
+    bar(f"{tag}.worst_grad_norm", worst[1], hard=1.5e-1 if bwd else 1e-1)
+    bar(f"{tag}.total_grad_norm", abs(total - float(g["grad_total_norm"])) / float(g["grad_total_norm"]), hard=5e-2 if bwd else 3e-2)
+    bar(f"{tag}.worst_tap", max(errs.values()), hard=1e-1)
 
 
 @pytest.mark.parametrize("case", ["tiny_pad", "tiny8", "b2_ragged"])
