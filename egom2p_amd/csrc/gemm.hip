@@ -235,12 +235,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 // registers (a lane owns 4 consecutive output columns: 8- / 16-byte stores), bit-identical results to the other NT kernels
 // up to the fp32 summation order inside the MFMA chain (same K order: identical here).
 // ---------------------------------------------------------------------------------------------
-constexpr int S64_STAGES = 4;
-constexpr int S64_TILE = 64 * 128;                 // one operand tile: 64 rows x 64 bf16 = 8 KiB
-constexpr int S64_STAGE = 2 * S64_TILE;            // A + B
-constexpr int NT64_LDS = S64_STAGES * S64_STAGE;   // 64 KiB: two workgroups per CU
+// Round 5: the same kernel for other tile shapes (template: TM x TN output tile, NS ring slots).  The generation path's ENCODER
+// linears run on 5120 ... 11948 rows: 180 - 1300 tiles of 128 x 128, i.e. one to three rounds of the persistent two-stage kernel
+// above, whose tile takes 12 K-steps x one exposed DMA round trip (~1 us each: 24 - 38 us per launch, rocprofv3
+// profiles/r05_eval_rgb2depth_before_kernel_stats.csv).  A 128 x 64 tile on a 3-deep ring (72 KiB: two workgroups per CU) keeps
+// two K-steps in flight, its K-step costs LDS reads + 16 MFMAs per wave, and the grid has twice the workgroups to fill rounds with.
+template <int TM, int TN, int NS>
+struct NTL {
+    static constexpr int PA = TM / 32, PB = TN / 32;          // LDS-DMA pieces (8 rows x 128 B) per wave, K-step and operand
+    static constexpr int TA = TM * 128, TB = TN * 128;        // operand tiles: rows x 64 bf16
+    static constexpr int STAGE = TA + TB;
+    static constexpr int LDS = NS * STAGE;
+    static constexpr int PER = PA + PB;                       // DMA instructions of a wave per K-step
+};
+constexpr int NT64_LDS = NTL<64, 64, 4>::LDS;        // 64 KiB: two workgroups per CU
+constexpr int NTL128x64_LDS = NTL<128, 64, 3>::LDS;  // 72 KiB: two workgroups per CU
+constexpr int NTL128x128_LDS = NTL<128, 128, 3>::LDS;   // 96 KiB: one workgroup per CU
 
-__global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(NTArgs p) {
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(256, (NTL<TM, TN, NS>::LDS <= 80 * 1024 ? 2 : 1)) void gemm_ntl_kernel(NTArgs p) {
+    using T = NTL<TM, TN, NS>;
+    constexpr int MI = TM / 32, NI = TN / 32;                 // 16 x 16 accumulator blocks of a wave: (TM / 2) x (TN / 2) outputs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,78 +266,84 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(NTArgs p) {
     int M = p.M;
     long moff = 0;
     if (p.m_range) { moff = p.m_range[0]; M = min(M, p.m_range[1]); }
-    const int tiles_n = (p.N + 63) >> 6;
+    const int tiles_n = (p.N + TN - 1) / TN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int row0 = (tile / tiles_n) * 64, col0 = (tile % tiles_n) * 64;
+    const int row0 = (tile / tiles_n) * TM, col0 = (tile % tiles_n) * TN;
     if (row0 >= M) return;
     const int nt = p.K / BK;
 
-    // staging: wave instruction (2 * wave + j) of either operand writes tile rows 8 (2 wave + j) .. +7 (1 KiB, lane-linear);
+    // staging: wave instruction (P * wave + j) of an operand writes tile rows 8 (P wave + j) .. +7 (1 KiB, lane-linear);
     // slot s of row r holds global chunk s ^ (r & 7).  Rows beyond M / N are clamped (they feed outputs that are never stored).
-    const bf16_t* ga[2];
-    const bf16_t* gb[2];
+    const bf16_t* ga[T::PA];
+    const bf16_t* gb[T::PB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * (2 * wave + j) + (lane >> 3);
-        const int c = ((lane & 7) ^ (r & 7)) * 8;
-        ga[j] = p.A + (moff + min(row0 + r, M - 1)) * p.lda + c;
-        gb[j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + c;
+    for (int j = 0; j < T::PA; ++j) {
+        const int r = 8 * (T::PA * wave + j) + (lane >> 3);
+        ga[j] = p.A + (moff + min(row0 + r, M - 1)) * p.lda + ((lane & 7) ^ (r & 7)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < T::PB; ++j) {
+        const int r = 8 * (T::PB * wave + j) + (lane >> 3);
+        gb[j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + ((lane & 7) ^ (r & 7)) * 8;
     }
     auto stage = [&](int s, int k0) {
-        char* sa = smem + s * S64_STAGE + wave * 2048;
+        char* sa = smem + s * T::STAGE + wave * T::PA * 1024;
+        char* sb = smem + s * T::STAGE + T::TA + wave * T::PB * 1024;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16(ga[j] + k0, sa + j * 1024);
-            glds16(gb[j] + k0, sa + S64_TILE + j * 1024);
-        }
+        for (int j = 0; j < T::PA; ++j) glds16(ga[j] + k0, sa + j * 1024);
+#pragma unroll
+        for (int j = 0; j < T::PB; ++j) glds16(gb[j] + k0, sb + j * 1024);
     };
 #pragma unroll
-    for (int s = 0; s < S64_STAGES - 1; ++s)
+    for (int s = 0; s < NS - 1; ++s)
         if (s < nt) stage(s, s * BK);
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int cur = 0;
     for (int kt = 0; kt < nt; ++kt) {
-        // K-step kt must have landed; the (at most two) younger steps in flight stay out: 4 DMA instructions per wave and step
-        const int younger = min(nt - 1 - kt, S64_STAGES - 2);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // K-step kt must have landed; the (at most NS - 2) younger steps in flight stay out: T::PER DMA instructions per wave and step
+        const int younger = min(nt - 1 - kt, NS - 2);
+        if (NS >= 4 && younger >= 2) vm_wait<2 * T::PER>();
+        else if (younger >= 1) vm_wait<T::PER>();
+        else vm_wait<0>();
         lds_barrier();                                   // ... for every wave; and every wave is done reading step kt - 1
-        if (kt + S64_STAGES - 1 < nt) stage(cur == 0 ? S64_STAGES - 1 : cur - 1, (kt + S64_STAGES - 1) * BK);
-        const char* sa = smem + cur * S64_STAGE;
-        const char* sb = sa + S64_TILE;
+        if (kt + NS - 1 < nt) stage(cur == 0 ? NS - 1 : cur - 1, (kt + NS - 1) * BK);
+        const char* sa = smem + cur * T::STAGE;
+        const char* sb = sa + T::TA;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[MI], bfr[NI];
             const int c = ks * 4 + (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ar = wm * 32 + i * 16 + (lane & 15);
+            for (int i = 0; i < MI; ++i) {
+                const int ar = wm * (TM / 2) + i * 16 + (lane & 15);
                 af[i] = *(const bf16x8*)(sa + ar * 128 + ((c ^ (ar & 7)) << 4));
-                const int br = wn * 32 + i * 16 + (lane & 15);
-                bfr[i] = *(const bf16x8*)(sb + br * 128 + ((c ^ (br & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NI; ++j) {
+                const int br = wn * (TN / 2) + j * 16 + (lane & 15);
+                bfr[j] = *(const bf16x8*)(sb + br * 128 + ((c ^ (br & 7)) << 4));
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
                     // operands swapped: D[row = n (4 regs)][col = m (lane & 15)]
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        cur = (cur + 1 == S64_STAGES) ? 0 : cur + 1;
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gm = row0 + wm * 32 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int gm = row0 + wm * (TM / 2) + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gn = col0 + wn * 32 + j * 16 + 4 * (lane >> 4);
+        for (int j = 0; j < NI; ++j) {
+            const int gn = col0 + wn * (TN / 2) + j * 16 + 4 * (lane >> 4);
             if (gm >= M || gn >= p.N) continue;
             const long mrow = moff + gm;
             f32x4 v = acc[i][j];
@@ -340,6 +364,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(NTArgs p) {
         }
     }
 }
+// the round-4 name of the 64 x 64 instantiation (profiles, tools)
+#define gemm_nt64_kernel (gemm_ntl_kernel<64, 64, 4>)
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel, 256x256 tile, 8 waves, staggered half-phases (for the large GEMMs).
@@ -1261,11 +1287,15 @@ int g_nt256 = 1;
 int g_tn256 = 1;
 int g_nt64_tiles = 400;      // NT launches of at most this many 128x128 tiles run on 64x64 tiles instead (0 = never; ego_gemm_small_tiles)
 int g_nt_dephase = 0;        // timing probe of the persistent 256 x 256 NT kernel (ego_gemm_tune key 1); 0 = product behaviour
+int g_ntl_force = 0;         // probe (ego_gemm_tune key 2): 1 = every non-256 NT launch on 128 x 64 tiles, 2 = on 128 x 128 (3-deep ring)
+int g_ntl_tiles = 0;         // NT launches of at most this many 128 x 128 tiles (and more than the 64 x 64 threshold) take the 128 x 64 low-latency kernel
 bool g_attr_done = false;
 void ensure_attrs() {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT64_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntl_kernel<128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NTL128x64_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntl_kernel<128, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, NTL128x128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT3_LDS);
@@ -1307,9 +1337,12 @@ extern "C" int ego_gemm_small_tiles(int max_tiles128) {
 extern "C" int ego_gemm_tune(int key, int value) {
     // probe hook (no reference counterpart; results never change): key 1 = start delay, in units of ~0.5 us, of every other
     // persistent 256 x 256 NT workgroup of an XCD.  Returns the previous value, value < 0 only queries.
-    if (key != 1) return -1;
-    const int old = g_nt_dephase;
-    if (value >= 0) g_nt_dephase = value;
+    // key 2 = force the low-latency tile family on every launch the 256 x 256 kernel does not take (1: 128 x 64, 2: 128 x 128);
+    // key 3 = largest 128 x 128 tile count sent to the 128 x 64 low-latency kernel (the product threshold).
+    int* v = key == 1 ? &g_nt_dephase : key == 2 ? &g_ntl_force : key == 3 ? &g_ntl_tiles : nullptr;
+    if (!v) return -1;
+    const int old = *v;
+    if (value >= 0) *v = value;
     return old;
 }
 
@@ -1339,6 +1372,51 @@ extern "C" int ego_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
         return EGO_OK;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // Grids of one to a few rounds (the generation path: 1707 ... 11948 rows): which family is fastest was measured per shape
+    // (tools/gen_gemm_sweep.py, profiles/r05_gen_gemm_sweep_*.log) and follows three rules - all families give the same bits:
+    //   * narrow outputs (N <= 768: q, proj) and the fp32 / residual epilogues: 64 x 64 tiles up to ~100 tiles of 128 x 128, then
+    //     128 x 64 tiles on the 3-deep ring up to ~520 (their register epilogues store whole 16-byte fp32 pieces; the two-stage
+    //     128 x 128 kernel pays an exposed DMA round trip per K-step and a slow ragged last row tile: 36 vs 25 us at 8534 rows);
+    //   * wider bf16 outputs: 128 x 64 tiles up to ~330 tiles of 128 x 128 (kv at <= 3414 rows, qkv at 1707);
+    //   * beyond that the launch time is (rounds) x (time of one tile) for either persistent kernel - a 256 x 256 tile takes about
+    //     1.85 x a 128 x 128 tile of the two-stage kernel at two workgroups per CU - so the 256 x 256 kernel is taken when
+    //     1.85 ceil(tiles256 / 256) <= ceil(tiles128 / 512): e.g. fc1||fc3 at 3414 rows 224 tiles = ONE round (25 vs 29 us), at
+    //     5120 rows 320 tiles = two rounds against three (45 vs 41 us: the 128 x 128 kernel stays).
+    // Device-side row ranges (m_range: the host M is only an upper bound) keep the round-4 choice.
+    if (g_nt256 == 1 && g_ntl_force == 0 && g_ntl_tiles == 0 && !m_range && g_nt64_tiles == 400) {
+        const bool narrow = N <= 768 || epi != EGO_EPI_BF16;
+        int pick = 0;                                   // 0: round-4 rule below, 1: 64 x 64, 2: 128 x 64, 3: 256 x 256
+        if (narrow) pick = tiles <= 100 ? 1 : tiles <= 520 ? 2 : 0;
+        else if (tiles <= 330) pick = 2;
+        else if (legal256 && 185 * ((tiles256 + 255) / 256) <= 100 * ((tiles + 511) / 512)) pick = 3;
+        if (pick == 1) {
+            EGO_LAUNCH(gemm_nt64_kernel, dim3(((M + 63) / 64) * ((N + 63) / 64)), dim3(256), NT64_LDS, stream, a);
+            LAUNCH_CHECK();
+            return EGO_OK;
+        }
+        if (pick == 2) {
+            EGO_LAUNCH((gemm_ntl_kernel<128, 64, 3>), dim3(((M + 127) / 128) * ((N + 63) / 64)), dim3(256), NTL128x64_LDS, stream, a);
+            LAUNCH_CHECK();
+            return EGO_OK;
+        }
+        if (pick == 3) {
+            if (epi == EGO_EPI_BF16) { EGO_LAUNCH(gemm_nt256_kernel<0>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+            else { EGO_LAUNCH(gemm_nt256_kernel<1>, dim3(tiles256 < 256 ? tiles256 : 256), dim3(512), NT3_LDS, stream, a); }
+            LAUNCH_CHECK();
+            return EGO_OK;
+        }
+    }
+    if (g_ntl_force == 2) {
+        EGO_LAUNCH((gemm_ntl_kernel<128, 128, 3>), dim3(tiles), dim3(256), NTL128x128_LDS, stream, a);
+        LAUNCH_CHECK();
+        return EGO_OK;
+    }
+    if (g_ntl_force == 1 || (tiles > g_nt64_tiles && tiles <= g_ntl_tiles)) {
+        // one to a few rounds of 128 x 128 tiles (the generation path's encoder linears): 128 x 64 tiles on a 3-deep ring
+        EGO_LAUNCH((gemm_ntl_kernel<128, 64, 3>), dim3(((M + 127) / 128) * ((N + 63) / 64)), dim3(256), NTL128x64_LDS, stream, a);
+        LAUNCH_CHECK();
+        return EGO_OK;
+    }
     // under-filled grids (the generation path's 1707-row linears): 64x64 tiles, four times the workgroups (gemm_nt64_kernel).
     // With a device-side row range the host M is only an upper bound: the grid is sized for it, surplus workgroups exit.
     if (g_nt64_tiles > 0 && tiles <= g_nt64_tiles) {

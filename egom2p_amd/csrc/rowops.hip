@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     // whatever hipcc packs or fuses in one instantiation and not in another)
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row bases stay scalar)
     if (row >= rows) return;
     // D = the normalised width, ld >= D = the row pitch of x and y (a model dimension stored padded: the columns [D, ld) of
     // x are zero and do not take part; those of y are written as zeros)
@@ -44,10 +44,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float* xr = x + (long)row * ld;
     f32x4 v[LN_MAXC];
     float s = 0.f;
+    // every chunk's load is issued before the first use (a chunk past the row re-reads the row's last chunk and is not used): with
+    // the load inside `if (c < nc)` hipcc kept each chunk's load and its sum in one exec-masked region and waited for every chunk in
+    // turn - at D = 1152 (4.5 chunks per lane) the forward ran 2.7 TB/s against 5.3 at D = 768 (tools/ln_bench.py, round 5)
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) v[i] = *(const f32x4*)(xr + min(lane + 64 * i, nc - 1) * 4);
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
-        if (c < nc) { v[i] = *(const f32x4*)(xr + c * 4); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+        if (c < nc) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) / D;
     float q = 0.f;
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wave)
 
+// (second launch-bound argument = waves per SIMD the register allocation must allow: the kernel lives on the rows it has in flight)
 template <int LN_MAXC, bool TAIL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const int* __restrict__ dy_row,
                                                      const float* __restrict__ x, const float* __restrict__ mean_in,
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     // whatever hipcc packs or fuses in one instantiation and not in another)
 #pragma clang fp contract(off)
     __shared__ float red[4][LN_MAXC * 64 * 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row offsets / statistics stay scalar)
     const int nc = (D + 3) >> 2, ncl = ld >> 2;      // D = normalised width, ld = row pitch (columns [D, ld): zero gradient)
     f32x4 ww[LN_MAXC], dwa[LN_MAXC];
 #pragma unroll
@@ -125,44 +131,73 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         dwa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         ww[i] = (c < nc) ? *(const f32x4*)(w + c * 4) : dwa[i];
     }
+    // (one row at a time per wave, no unrolling across rows: with the row loop unrolled hipcc kept two rows' registers alive - 122 /
+    //  198 / 248 VGPRs at 3 / 4 / 6 chunks per lane, i.e. 4 / 2 / 2 waves per SIMD - and the kernel, which lives on the number of
+    //  rows in flight, fell from 5.0 TB/s at D = 768 to 3.3 at D = 1152 (tools/ln_bench.py, round 5).  g = dy w and xhat are
+    //  formed twice - before and after the two row reductions, by the same expressions, so bit for bit the same values - instead
+    //  of being held across them.)
+#pragma unroll 1
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
         if (row >= rows) break;
         const int grow = dy_row ? dy_row[row] : row;
         const float mean = mean_in[row], rstd = rstd_in[row];
         const float* xr = x + (long)row * ld;
-        f32x4 g[LN_MAXC], xh[LN_MAXC];
+        // all loads of the row first (branch-free: a chunk past the row re-reads the last chunk, a row without a gradient reads row 0
+        // and is masked below): with the loads inside `if (c < nc)` every chunk waited for its own round trip (see ln_fwd_kernel)
+        f32x4 xv[LN_MAXC], pin[LN_MAXC];
+        u32x2 raws[LN_MAXC];
+        const bf16_t* dyr = dy + (long)max(grow, 0) * ld;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int cc = min(lane + 64 * i, nc - 1);
+            xv[i] = *(const f32x4*)(xr + cc * 4);
+            raws[i] = *(const u32x2*)(dyr + cc * 4);
+        }
+        if (dx_in) {          // the residual-stream gradient this row is added to: in flight under the two wave reductions
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) pin[i] = *(const f32x4*)(dx_in + (long)row * ld + min(lane + 64 * i, nc - 1) * 4);
+        }
+        auto dy4 = [&](int i) {
+            const u32x2 raw = raws[i];
+            return grow >= 0 ? f32x4{bf16_to_f32(raw[0] & 0xffff), bf16_to_f32(raw[0] >> 16), bf16_to_f32(raw[1] & 0xffff), bf16_to_f32(raw[1] >> 16)}
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nc) {
-                const f32x4 xv = *(const f32x4*)(xr + c * 4);
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-                if (grow >= 0) {
-                    const u32x2 raw = *(const u32x2*)(dy + (long)grow * ld + c * 4);
-                    d = f32x4{bf16_to_f32(raw[0] & 0xffff), bf16_to_f32(raw[0] >> 16), bf16_to_f32(raw[1] & 0xffff), bf16_to_f32(raw[1] >> 16)};
-                }
+                const f32x4 d = dy4(i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[i][e] = (xv[e] - mean) * rstd;
-                    g[i][e] = d[e] * ww[i][e];
-                    dwa[i][e] += d[e] * xh[i][e];
-                    s1 += g[i][e];
-                    s2 += g[i][e] * xh[i][e];
+                    const float xh = (xv[i][e] - mean) * rstd;
+                    const float ge = d[e] * ww[i][e];
+                    dwa[i][e] += d[e] * xh;
+                    s1 += ge;
+                    s2 += ge * xh;
                 }
             }
         }
         const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+        // (opaque to the optimiser: without it hipcc recognises the second pass's expressions and keeps every g / xhat of the first
+        //  pass in registers after all - 102 VGPRs at 3 chunks instead of 70)
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) asm volatile("" : "+v"(xv[i]), "+v"(raws[i]));
 #pragma unroll
         for (int i = 0; i < LN_MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nc) {
+                const f32x4 d = dy4(i);
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (!TAIL || c * 4 + e < D) ? mul_rounded(rstd, g[i][e] - c1 - xh[i][e] * c2) : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[i][e] - mean) * rstd;
+                    const float ge = d[e] * ww[i][e];
+                    o[e] = (!TAIL || c * 4 + e < D) ? mul_rounded(rstd, ge - c1 - xh * c2) : 0.f;
+                }
                 if (dx_in) {      // (term rounded, then added - no fma contraction: ln_bwd_multi_kernel sums its layers the same way, bit for bit)
-                    const f32x4 p_ = *(const f32x4*)(dx_in + (long)row * ld + c * 4);
+                    const f32x4 p_ = pin[i];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = mul_then_add(o[e], 1.0f, p_[e]);
                 }
@@ -208,16 +243,21 @@ __global__ __launch_bounds__(256) void ln_fwd_multi_kernel(LnMultiFwd a) {
     // whatever hipcc packs or fuses in one instantiation and not in another)
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int D = a.D, nc = (D + 3) >> 2, ncl = a.ld >> 2;
     const float* xr = a.x + (long)row * a.ld;
     f32x4 v[LN_MAXC];
     float s = 0.f;
+    // every chunk's load is issued before the first use (a chunk past the row re-reads the row's last chunk and is not used): with
+    // the load inside `if (c < nc)` hipcc kept each chunk's load and its sum in one exec-masked region and waited for every chunk in
+    // turn - at D = 1152 (4.5 chunks per lane) the forward ran 2.7 TB/s against 5.3 at D = 768 (tools/ln_bench.py, round 5)
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) v[i] = *(const f32x4*)(xr + min(lane + 64 * i, nc - 1) * 4);
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
-        if (c < nc) { v[i] = *(const f32x4*)(xr + c * 4); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+        if (c < nc) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) / D;
     float q = 0.f;

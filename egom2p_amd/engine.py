@@ -160,6 +160,7 @@ class Engine:
         self.attn_groups = os.environ.get("EGOM2P_ATTN_GROUPS", "1") != "0"
         self.attn_split = os.environ.get("EGOM2P_ATTN_SPLIT", "1") != "0"       # generation path: split keys on under-filled grids
         self.cfg_pair = os.environ.get("EGOM2P_CFG_PAIR", "1") != "0"           # guided step: cond + uncond share one decoder pass
+        self.gen_overlap = os.environ.get("EGOM2P_GEN_OVERLAP", "0") == "1"     # generation: independent launches on a second stream (_fork)
         # every decoder layer's context_norm normalises the SAME context tensor: one fused launch forward (x and its statistics
         # read once, one output per layer) and one backward (x once, one write of the context gradient) instead of one per layer
         self.ctx_ln_fused = (os.environ.get("EGOM2P_CTX_LN_FUSED", "1") != "0" and not self.fp8_forward and self.D <= 1536
@@ -169,6 +170,31 @@ class Engine:
         """What the PHYSICAL flat buffers (P, G and the optimiser's m / v) depend on beyond the model: saved with optimiser
         checkpoints and checked on load (a resume under another EGOM2P_HEAD_PAD must not die in a bare copy_)."""
         return (2, int(self.n_flat), int(self.D), int(self.Hs), int(self.HDP), int(self.Fp))    # 2: context_norm weights in one group (round 5)
+
+    # ---- generation path: independent launches of an under-filled pass beside each other (round 5) ----------------------------------
+    # At batch 1 the rgb -> depth passes are latency-bound (3414 decoder rows fill a third of the chip; the unconditional
+    # encoder group's self-attention is 324 workgroups for 768 slots), and several of their launches do not depend on each other:
+    # the cross-attention kv projections of ALL decoder layers depend only on the context, the two halves of a guided step's
+    # cross-attention and the two encoder groups' self-attention launches are independent.  They go to a second stream (fork / join
+    # by stream waits, which a hipGraph capture turns into parallel branches); EGOM2P_GEN_OVERLAP=0 keeps one stream.
+    def _fork(self, fn, which: int = 0):
+        """run fn on side stream `which` (0: the launch beside the current one, 1: the decoder's kv side chain - a long-lived
+        branch that must not sit in front of the short ones), ordered after everything issued on the current stream so far"""
+        if not self.gen_overlap:
+            fn()
+            return None
+        key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), "gen", which)
+        if key not in _PAIR_STREAMS:
+            _PAIR_STREAMS[key] = torch.cuda.Stream(device=self.dev)      # (one per device and process: a stream is a hardware queue)
+        side, main = _PAIR_STREAMS[key], torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        return side
+
+    def _join(self, side):
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def _ring_next(self):
         self._ring_i = (self._ring_i + 1) % len(self.ring_b)
@@ -631,7 +657,9 @@ class Engine:
             q = self._quant(xn, rows, l.in_f)
             ops.gemm_nt_swiglu_fwd_fp8(q, self.qs, l.w8, l.s8, ab, h, rows, self.Fp, l.in_f)
             return
-        if ops.swiglu_fwd_fusable(self.Fp, l.in_f) and rows >= 4096:
+        # (fused launch from 3000 rows on: at 3414 rows - the paired decoder passes of a guided generation step - 29 us against 35 for
+        #  GEMM + gate pass; at 1707 rows the two launches win, 22 against 27: profiles/r05_gen_gemm_sweep_after.log)
+        if ops.swiglu_fwd_fusable(self.Fp, l.in_f) and rows >= 3000:
             ops.gemm_nt_swiglu_fwd(xn, l.wb, ab, h, rows, self.Fp, l.in_f, ldx=xn.shape[-1], ldw=l.in_f)
         else:
             self._lin_fwd(f"{pre}.mlp.fc13", xn, ab, rows)
@@ -681,23 +709,41 @@ class Engine:
     SPLIT_TARGET_WGS = 640
 
     def _kv_splits(self, B, Nq, Nk):
+        """Key runs per query tile of a generation-path attention launch (ego_attn_fwd_d64_split), from the measured table
+        profiles/r05_gen_attn_split_sweep_before.log (one sample, 12 heads; us per launch unsplit / best split):
+          168 workgroups (1707 queries): 1707 keys 28 / - (unsplit wins), 3414 keys 47 / 38 (3 runs), 8534 keys 105 / 67 (3 runs);
+          324 (3414 x 3414): 66 / 62 (2 runs);  480, 648 (5120, 6827 rows): unsplit wins (99, 173 us: one full round of 768 slots);
+          804 (8534 rows: 36 workgroups more than the 768 slots of one round): 299 / 275 (3 runs even out the tail).
+        Round 4 split whenever fewer than 640 workgroups existed (1707 x 1707: 32 us against 28 unsplit)."""
         base = B * self.Hs * ((Nq + 127) // 128)
-        if self.HDP != 64 or base <= 0 or not self.attn_split:
+        if self.HDP != 64 or base <= 0 or not self.attn_split or Nk < 2048:
             return 1
-        s = min(8, self.SPLIT_TARGET_WGS // base, ((Nk + 63) // 64) // 4)       # at least four 64-key tiles per run
-        return max(1, s)
+        slots = 768                                           # three 4-wave workgroups per CU
+        if base <= 200:
+            s = 3
+        elif base <= 400:
+            s = 2
+        elif slots < base <= slots + slots // 2:              # a short second round: cut every tile's keys so the rounds even out
+            s = 3
+        else:
+            s = 1
+        return max(1, min(s, ((Nk + 63) // 64) // 4))         # at least four 64-key tiles per run
 
-    def _attn_infer(self, w, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, ks, ke, B, Nq, Nk):
-        """`_attn` of the generation passes: one interval per sample, no LSE consumer, split keys when the grid is small"""
+    def _attn_infer(self, w, q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, ks, ke, B, Nq, Nk, lane=0):
+        """`_attn` of the generation passes: one interval per sample, no LSE consumer, split keys when the grid is small.
+        lane = 1: a launch that runs BESIDE another attention launch (_fork): its own split scratch and LSE rows"""
         A = self.A
         sp = self._kv_splits(B, Nq, Nk)
-        ws = w.get("att_ws")
+        wkey, lkey = ("att_ws", "lse") if lane == 0 else ("att_ws2", "lse2")
+        ws = w.get(wkey)
+        if sp > 1 and ws is not None and ws.numel() < ops.attn_fwd_split_floats(B, self.Hs, Nq, sp) and not torch.cuda.is_current_stream_capturing():
+            ws = w[wkey] = torch.empty(ops.attn_fwd_split_floats(B, self.Hs, Nq, sp) + 4096, device=self.dev, dtype=F32)
         if sp > 1 and ws is not None and ws.numel() >= ops.attn_fwd_split_floats(B, self.Hs, Nq, sp):
             ops.attn_fwd_split(q_t.data_ptr() + 2 * q_off, Nq * q_rs, q_rs, kv_t.data_ptr() + 2 * k_off, Nk * kv_rs, kv_rs,
-                               kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, w["lse"], ks, ke, 1, 0,
+                               kv_t.data_ptr() + 2 * v_off, Nk * kv_rs, kv_rs, o_t.data_ptr(), Nq * A, A, w[lkey], ks, ke, 1, 0,
                                B, self.Hs, Nq, Nk, self.scale, sp, ws)
         else:
-            self._attn(q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, w["lse"], ks, ke, 1, 0, B, Nq, Nk)
+            self._attn(q_t, q_off, q_rs, kv_t, k_off, v_off, kv_rs, o_t, w[lkey], ks, ke, 1, 0, B, Nq, Nk)
 
     def _dec_groups(self):
         """Row groups of the decoder's block-diagonal self-attention mask for the attention kernels (head dim 64): the
@@ -1060,7 +1106,14 @@ class Engine:
         # every decoder layer's context_norm output from one pass over the context (ego_layernorm_fwd_multi)
         w["cns"] = [e(RC, D) for _ in range(self.cfg.decoder_depth)] if self.ctx_ln_fused else None
         # scratch of the split-key attention launches: splits x B x H x ceil(Nq / 128) <= SPLIT_TARGET_WGS bounds it
-        w["att_ws"] = e(self.SPLIT_TARGET_WGS * 128 * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split) else None
+        # (sized for the largest split launch of a pass: 3 runs over max(Nmax, Mmax) query rows of G * B samples)
+        w["att_ws"] = (e(3 * G * B * H * max(Nmax, Mmax) * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split) else None)
+        # a second attention launch beside the first (_fork): its own scratch and LSE rows; one kv buffer per decoder layer when the
+        # kv projections run as a side chain
+        w["att_ws2"] = (e(3 * B * H * max(Nmax, Mmax) * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split and G > 1 and self.gen_overlap) else None)
+        w["lse2"] = e(G * B, H, max(Nmax, Mmax), dt=F32) if (G > 1 and self.gen_overlap) else None
+        w["st2"] = e(2, RC, dt=F32) if self.gen_overlap else None
+        w["kvs"] = ([e(RC, 2 * A) for _ in range(self.cfg.decoder_depth)] if (self.gen_overlap and self.ctx_ln_fused) else None)
         if not fresh:
             self._iw, self._infer_key = w, key
         return w
@@ -1087,9 +1140,17 @@ class Engine:
             pre = f"encoder.{i}"
             self._ln(x[:R], f"{pre}.norm1.weight", w["ln"], w["st"])
             self._lin_fwd(f"{pre}.attn.qkv.weight", w["ln"], w["qkv"], R)
-            for side, _, N, r0 in parts:
+            def enc_attn(gi):
+                side, _, N, r0 = parts[gi]
                 self._attn_infer(w, w["qkv"], r0 * 3 * A, 3 * A, w["qkv"], r0 * 3 * A + A, r0 * 3 * A + 2 * A, 3 * A, w["ao"][r0:], w["zero_b"],
-                                 side["n_valid"], B, N, N)
+                                 side["n_valid"], B, N, N, lane=1 if (gi == 1 and w.get("lse2") is not None) else 0)
+            # the second group's self-attention (the unconditional inputs: 324 workgroups at 3414 rows) goes out first, on the second
+            # stream, and runs beside the first group's launch
+            forked = self._fork(lambda: enc_attn(1)) if (len(parts) == 2 and w.get("lse2") is not None) else None
+            enc_attn(0)
+            if len(parts) == 2 and w.get("lse2") is None:
+                enc_attn(1)
+            self._join(forked)
             self._lin_fwd(f"{pre}.attn.proj.weight", w["ao"], xn, R, L.EPI_RESID, R=x)
             self._ln(xn[:R], f"{pre}.norm2.weight", w["ln"], w["st"])
             self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], R)
@@ -1120,7 +1181,22 @@ class Engine:
                       w["dslot"], local, w["dtok"], y, None, RD, D)
         w["full_m"].fill_(M)
         fused = self.ctx_ln_fused and w.get("cns") is not None and RC > 0
-        if fused:
+        kv_side, kv_evs = None, None
+        if fused and w.get("kvs") is not None and RQ > 0:
+            # side chain: every layer's context LayerNorm output (one fused launch) and kv projection depend on the context only -
+            # they run on the second stream beside the decoder's self-attention blocks; layer i's cross-attention waits for kv i
+            kv_evs = [torch.cuda.Event() for _ in range(cfg.decoder_depth)]
+
+            def chain():
+                ops.layernorm_fwd_multi(w["ctx"][:RC], [self.p[f"decoder.{i}.context_norm.weight"] for i in range(cfg.decoder_depth)],
+                                        w["cns"], w["st2"][0], w["st2"][1], eps=cfg.eps, width=self.Dl)
+                for i in range(cfg.decoder_depth):
+                    self._lin_fwd(f"decoder.{i}.cross_attn.kv.weight", w["cns"][i], w["kvs"][i], RC)
+                    kv_evs[i].record(torch.cuda.current_stream())
+            kv_side = self._fork(chain, which=1)
+            if kv_side is None:
+                kv_evs = None
+        elif fused:
             ops.layernorm_fwd_multi(w["ctx"][:RC], [self.p[f"decoder.{i}.context_norm.weight"] for i in range(cfg.decoder_depth)],
                                     w["cns"], w["st"][0], w["st"][1], eps=cfg.eps, width=self.Dl)
         for i in range(cfg.decoder_depth):
@@ -1133,12 +1209,28 @@ class Engine:
                 self._ln(yn[:RQ], f"{pre}.query_norm.weight", w["ln"], w["st"])
                 self._lin_fwd(f"{pre}.cross_attn.q.weight", w["ln"], w["q"], RQ)
                 cn = w["cns"][i] if fused else w["cn"]
-                if not fused:
-                    self._ln(w["ctx"][:RC], f"{pre}.context_norm.weight", cn, w["st"])
-                self._lin_fwd(f"{pre}.cross_attn.kv.weight", cn, w["kv"], RC)
-                for g, (side, n, c0) in enumerate(parts[:n_ctx]):
-                    self._attn_infer(w, w["q"], g * RM * A, A, w["kv"], c0 * 2 * A, c0 * 2 * A + A, 2 * A, w["ao"][g * RM:], w["zero_b"],
-                                     side["n_valid"], B, M, n)
+                kvb = w["kv"]
+                if kv_side is not None or (fused and w.get("kvs") is not None and RQ > 0):
+                    kvb = w["kvs"][i]                          # made by the side chain (or, one stream: in line, at the top)
+                    if kv_evs is not None:
+                        torch.cuda.current_stream().wait_event(kv_evs[i])
+                else:
+                    if not fused:
+                        self._ln(w["ctx"][:RC], f"{pre}.context_norm.weight", cn, w["st"])
+                    self._lin_fwd(f"{pre}.cross_attn.kv.weight", cn, kvb, RC)
+
+                def cross(g):
+                    side, n, c0 = parts[g]
+                    self._attn_infer(w, w["q"], g * RM * A, A, kvb, c0 * 2 * A, c0 * 2 * A + A, 2 * A, w["ao"][g * RM:], w["zero_b"],
+                                     side["n_valid"], B, M, n, lane=1 if (g == 1 and w.get("lse2") is not None) else 0)
+                # the two halves of a guided step attend different contexts: the second half beside the first
+                forked = self._fork(lambda: cross(1)) if (n_ctx == 2 and w.get("lse2") is not None) else None
+                cross(0)
+                if n_ctx == 2 and w.get("lse2") is None:
+                    cross(1)
+                for g in range(2, n_ctx):
+                    cross(g)
+                self._join(forked)
                 self._lin_fwd(f"{pre}.cross_attn.proj.weight", w["ao"], y, RQ, L.EPI_RESID, R=yn)
                 if RQ < RD:
                     y[RQ:RD].copy_(yn[RQ:RD])
@@ -1150,6 +1242,7 @@ class Engine:
             self._mlp_gate_fwd(pre, w["ln"], w["ab"], w["h"], RD)
             self._lin_fwd(f"{pre}.mlp.fc2.weight", w["h"], yn, RD, L.EPI_RESID, R=y)
             y, yn = yn, y
+        self._join(kv_side)                                  # (every kv event has been waited for; a capture wants the branch joined)
         self._ln(y[:RD], "decoder_norm.weight", w["ln"], w["st"])
         l = self.lin[self.logit_key[tm.name]]
         logits = out if out is not None else torch.empty(RD, tm.vocab_size, device=self.dev, dtype=BF16)

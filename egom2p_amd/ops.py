@@ -167,6 +167,12 @@ def gemm_small_tiles(max_tiles128):
     return L.load().ego_gemm_small_tiles(int(max_tiles128))
 
 
+def gemm_tune(key, value):
+    """ego_gemm_tune: probe / tuning hook (1: start delay of every other persistent NT workgroup, 2: force the low-latency tile
+    family - 1 = 128 x 64, 2 = 128 x 128 -, 3: largest 128 x 128 tile count sent to the 128 x 64 kernel); returns the old value"""
+    return L.load().ego_gemm_tune(int(key), int(value))
+
+
 def tn_splits(Ni, Nj, rows, slab_numel, ranged=False, ldp=None, ldq=None):
     """Split-K factor for `gemm_tn`, asked from the launcher itself (ego_gemm_tn_plan)."""
     return L.load().ego_gemm_tn_plan(Ni, Nj, rows, Ni if ldp is None else ldp, Nj if ldq is None else ldq, slab_numel, int(ranged))

@@ -82,8 +82,11 @@ def test_gemm_nt_small_grid_kernel_equals_the_128_tile_kernel(M, N, K):
     outs = {}
     old = ops.gemm_small_tiles(-1)
     try:
-        for mode, thr in (("t128", 0), ("t64", 1 << 30)):
+        # t128x64 / t128x128 (round 5): the same kernel template on 128 x 64 and 128 x 128 tiles with a 3-deep ring (the generation
+        # path's encoder linears: one to three rounds of 128 x 128 tiles)
+        for mode, thr, force in (("t128", 0, 0), ("t64", 1 << 30, 0), ("t128x64", 0, 1), ("t128x128", 0, 2)):
             ops.gemm_small_tiles(thr)
+            ops.gemm_tune(2, force)
             ops.gemm_kernel_mode(0, 1)                       # keep the 256x256 family out of the comparison
             C = torch.full((M + 2, N), 5.0, device=DEV, dtype=torch.bfloat16)
             ops.gemm_nt(A, B, C, M, N, K, L.EPI_BF16)
@@ -98,9 +101,11 @@ def test_gemm_nt_small_grid_kernel_equals_the_128_tile_kernel(M, N, K):
             outs[mode] = (C, C32, o1, o2, Cr)
     finally:
         ops.gemm_small_tiles(old)
+        ops.gemm_tune(2, 0)
         ops.gemm_kernel_mode(1, 1)
-    for a, b in zip(outs["t128"], outs["t64"]):
-        assert torch.equal(a, b)
+    for other in ("t64", "t128x64", "t128x128"):
+        for a, b in zip(outs["t128"], outs[other]):
+            assert torch.equal(a, b), other
     C, C32, o1, o2, Cr = outs["t64"]
     ref = A.float() @ B.float().t()
     assert _rel(C32[:M], ref) < 1e-5 and (C32[M:] == 3).all() and (C[M:] == 5).all()

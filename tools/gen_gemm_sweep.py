@@ -39,25 +39,42 @@ def main():
     D, A, F = 768, 768, 2048
     rows_list = [int(x) for x in os.environ.get("ROWS", "1707,3414,5120,6827,8534,10241,11948").split(",")]
     shapes = [("qkv", 3 * A, D, L.EPI_BF16), ("proj+res", D, A, L.EPI_RESID), ("fc2+res", D, F, L.EPI_RESID), ("fc13", 2 * F, D, L.EPI_BF16),
-              ("q", A, D, L.EPI_BF16), ("kv", 2 * A, D, L.EPI_BF16)]
-    modes = {"64": (0, 1 << 30), "128": (0, 0), "256": (2, 0), "auto": (1, 400)}       # (ego_gemm_kernel_mode nt256, ego_gemm_small_tiles)
+              ("q", A, D, L.EPI_BF16), ("kv", 2 * A, D, L.EPI_BF16), ("logits", 64000, D, L.EPI_BF16)]
+    # (ego_gemm_kernel_mode nt256, ego_gemm_small_tiles, ego_gemm_tune key 2): 128x64 / 128x128 = the round-5 low-latency instantiations
+    modes = {"64": (0, 1 << 30, 0), "128": (0, 0, 0), "128x64": (0, 0, 1), "128x128": (0, 0, 2), "256": (2, 0, 0), "auto": (1, 400, 0)}
     print(f"{'shape':10s} {'rows':>6s} | " + " ".join(f"{m:>9s}" for m in modes) + " | best")
     for name, N, K, epi in shapes:
-        for M in rows_list:
+        for M in (rows_list if name != "logits" else [1707, 3414]):
             x = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
             w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
             r = torch.randn(M, N, device=dev) if epi == L.EPI_RESID else None
             y = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == L.EPI_RESID else torch.bfloat16)
             res = {}
-            for m, (nt256, small) in modes.items():
+            for m, (nt256, small, force) in modes.items():
                 lib.ego_gemm_kernel_mode(nt256, 1)
                 lib.ego_gemm_small_tiles(small)
+                lib.ego_gemm_tune(2, force)
                 res[m] = timeit(lambda: ops.gemm_nt(x, w, y, M, N, K, epi, R=r))
             lib.ego_gemm_kernel_mode(1, 1)
             lib.ego_gemm_small_tiles(400)
-            best = min(("64", "128", "256"), key=lambda m: res[m])
+            lib.ego_gemm_tune(2, 0)
+            best = min((m for m in modes if m != "auto"), key=lambda m: res[m])
             print(f"{name:10s} {M:6d} | " + " ".join(f"{res[m]:9.1f}" for m in modes) + f" | {best} ({100 * (res['auto'] / res[best] - 1):+.0f} % vs auto)", flush=True)
             del x, w, y, r
+    # fc1||fc3 + gate: the fused 256 x 256 launch (gemm_nt256_kernel<3>) against the plain GEMM (selector's choice) + ego_swiglu_fwd
+    print("fc13 + gate: fused launch vs GEMM + swiglu pass (us)")
+    for M in rows_list:
+        x = (torch.randn(M, D, device=dev) * 0.5).bfloat16()
+        w = (torch.randn(2 * F, D, device=dev) * 0.05).bfloat16()
+        ab = torch.empty(M, 2 * F, device=dev, dtype=torch.bfloat16)
+        h = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+        t_f = timeit(lambda: ops.gemm_nt_swiglu_fwd(x, w, ab, h, M, F, D))
+
+        def two():
+            ops.gemm_nt(x, w, ab, M, 2 * F, D, L.EPI_BF16)
+            ops.swiglu_fwd(ab, h, M, F)
+        t_2 = timeit(two)
+        print(f"gate       {M:6d} | fused {t_f:8.1f}   two launches {t_2:8.1f}", flush=True)
 
 
 if __name__ == "__main__":

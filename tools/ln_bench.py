@@ -17,7 +17,7 @@ def timeit(fn, iters=20):
 
 
 res = {}
-for rows, D in [(65536, 768), (131072, 768), (32768, 1152)]:
+for rows, D in [(131072, 768), (65536, 768), (65536, 1024), (65536, 1152), (131072, 1152), (65536, 1536)]:
     x = torch.randn(rows, D, device="cuda"); w = torch.rand(D, device="cuda") + 0.5
     y = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
     mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
