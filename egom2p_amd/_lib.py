@@ -59,6 +59,7 @@ _SIGS = {
     "ego_gemm_kernel_mode": [i32, i32],
     "ego_gemm_small_tiles": [i32],
     "ego_gemm_tune": [i32, i32],
+    "ego_attn_tune": [i32, i32],
     "ego_compact": [C.POINTER(CompactDesc), i32, vp],
     "ego_embed_fwd": [C.POINTER(EmbedDesc), vp],
     "ego_embed_bwd_work_floats": [i64, i32, i32],

@@ -51,7 +51,9 @@ struct AttnArgs {
     bf16_t* dQ; long dq_bs, dq_rs;
     bf16_t* dK; long dk_bs, dk_rs;
     bf16_t* dV; long dv_bs, dv_rs;
+    int stagger;                // probe (ego_attn_tune key 1): start delay, in 512-clock units, of every other 256-workgroup wave of the grid
 };
+int g_attn_stagger = 0;         // probe state behind ego_attn_tune (0 = product behaviour); results never depend on it
 
 // (pair_tile: workgroup id -> ((batch, head) pair, tile), XCD-aware - common.h)
 
@@ -715,6 +717,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     } else if (tile * 128 >= p.Nk) {
         return;
     }
+    // Phase probe: two workgroups share a CU, one wave of each per SIMD, nothing holds them in opposite
+    // phases of their MFMA / vector-work alternation.  With p.stagger > 0 the workgroups dispatched as the SECOND on their CU (ids
+    // 256 .. 511 of every 512) start p.stagger x 512 clocks late; equal-length workgroups keep that offset through the launch.
+    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     const int kw0 = kg0 + tile * 128 + wave * 32;
     const int kl = lane & 31, hh = lane >> 5;
     const int kidx = kw0 + kl;
@@ -1002,6 +1009,15 @@ bool check_seg(const AttnArgs& a) {
 
 }  // namespace
 
+extern "C" int ego_attn_tune(int key, int value) {
+    // probe hook (timing only; no reference counterpart): key 1 = start delay (x 512 clocks) of the dK / dV workgroups that are the
+    // second on their CU.  Returns the previous value; value < 0 only queries; unknown key: -1.
+    if (key != 1) return -1;
+    const int old = g_attn_stagger;
+    if (value >= 0) g_attn_stagger = value;
+    return old;
+}
+
 extern "C" int ego_attn_fwd_d64_seg(const void* Q, long q_bs, long q_rs, const void* K, long k_bs, long k_rs,
                                     const void* V, long v_bs, long v_rs, void* O, long o_bs, long o_rs, void* O_lo, float* LSE,
                                     const int* ks, const int* ke, long r_bs, long r_rs, const int* seg, int n_seg, const int* seg_bad,
@@ -1075,6 +1091,7 @@ extern "C" int ego_attn_bwd_d64_seg(const void* Q, long q_bs, long q_rs, const v
     a.dQ = (bf16_t*)dQ; a.dq_bs = dq_bs; a.dq_rs = dq_rs;
     a.dK = (bf16_t*)dK; a.dk_bs = dk_bs; a.dk_rs = dk_rs;
     a.dV = (bf16_t*)dV; a.dv_bs = dv_bs; a.dv_rs = dv_rs;
+    a.stagger = g_attn_stagger;
     if (B == 0 || Nq == 0) return EGO_OK;
     if (!check(a) || !check_seg(a) || do_rs % 8 || do_bs % 8 || dq_rs % 8 || dk_rs % 8 || dv_rs % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8 ||
         o_rs % 4 || o_bs % 4 || ((((uintptr_t)dQ) | ((uintptr_t)dK) | ((uintptr_t)dV)) & 15)) return EGO_ERR_ARG;              // 16-byte gradient rows

@@ -1106,11 +1106,20 @@ class Engine:
         # every decoder layer's context_norm output from one pass over the context (ego_layernorm_fwd_multi)
         w["cns"] = [e(RC, D) for _ in range(self.cfg.decoder_depth)] if self.ctx_ln_fused else None
         # scratch of the split-key attention launches: splits x B x H x ceil(Nq / 128) <= SPLIT_TARGET_WGS bounds it
-        # (sized for the largest split launch of a pass: 3 runs over max(Nmax, Mmax) query rows of G * B samples)
-        w["att_ws"] = (e(3 * G * B * H * max(Nmax, Mmax) * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split) else None)
+        # (sized for the largest split launch this workspace can see: an encoder group's self-attention, the decoder's self-attention
+        #  over all groups, one group's cross-attention - whatever _kv_splits would split; shorter passes through the same buffers
+        #  split less or not at all)
+        need = 0
+        if self.HDP == 64 and self.attn_split:
+            for b_, nq, nk in ((B, Nmax, Nmax), (G * B, Mmax, Mmax), (B, Mmax, Nmax)):
+                for nq_ in {nq, max(1, nq // 2), max(1, nq // 4)}:          # (the split rule is not monotonic in the row count)
+                    sp_ = max(self._kv_splits(b_, nq_, nk), self._kv_splits(b_, nq_, max(1, nk // 2)))
+                    if sp_ > 1:
+                        need = max(need, int(ops.attn_fwd_split_floats(b_, H, nq_, sp_)))
+        w["att_ws"] = e(need + 4096, dt=F32) if (self.HDP == 64 and self.attn_split) else None
         # a second attention launch beside the first (_fork): its own scratch and LSE rows; one kv buffer per decoder layer when the
         # kv projections run as a side chain
-        w["att_ws2"] = (e(3 * B * H * max(Nmax, Mmax) * 66 + 4096, dt=F32) if (self.HDP == 64 and self.attn_split and G > 1 and self.gen_overlap) else None)
+        w["att_ws2"] = (e(need + 4096, dt=F32) if (self.HDP == 64 and self.attn_split and G > 1 and self.gen_overlap) else None)
         w["lse2"] = e(G * B, H, max(Nmax, Mmax), dt=F32) if (G > 1 and self.gen_overlap) else None
         w["st2"] = e(2, RC, dt=F32) if self.gen_overlap else None
         w["kvs"] = ([e(RC, 2 * A) for _ in range(self.cfg.decoder_depth)] if (self.gen_overlap and self.ctx_ln_fused) else None)

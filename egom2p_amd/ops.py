@@ -419,10 +419,12 @@ def sample_cfg_topp(cond, uncond, V, cfg_scale, top_p, temperature, uniforms, ou
 def top_k_count(top_k, V: int) -> int:
     """The k of `top_k_top_p_filtering` (egom2p/models/generate.py:335-342): an int is a count, a float a share of the vocabulary;
     0 / 0.0 = no top-k filter.  k = 0 from a tiny positive share makes torch.topk(..., 0)[0][..., -1] raise in the reference."""
-    if not top_k or top_k <= 0:
+    if top_k is None:
         return 0
     if isinstance(top_k, bool) or not isinstance(top_k, (int, float)):
-        raise ValueError(f"Invalid value for top_k: {top_k}")
+        raise ValueError(f"Invalid value for top_k: {top_k}")          # the reference's message (:342)
+    if top_k <= 0:
+        return 0
     k = min(top_k, V) if isinstance(top_k, int) else min(int(top_k * V), V)
     if k <= 0:
         raise ValueError(f"top_k = {top_k} keeps no token of a {V}-token vocabulary")

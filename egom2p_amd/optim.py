@@ -129,7 +129,12 @@ class FusedAdamW:
 
     def load_state_dict(self, sd):
         have, want = sd.get("layout"), self.engine.layout_tag()
-        if have is not None and tuple(have) != tuple(want):
+        if have is None:
+            # (before round 5 the state carried no tag, and round 5 moved the decoder's context_norm weights inside the flat buffers:
+            #  the element counts agree, the element ORDER does not - copying would misalign every moment behind `bridge` silently)
+            raise RuntimeError("optimizer state without a storage-layout tag (saved before round 5): the flat parameter order changed since; "
+                               "restart the optimizer state (the model state dict, keyed by name, still loads)")
+        if tuple(have) != tuple(want):
             raise RuntimeError(f"optimizer state was saved for storage layout {tuple(have)}, this engine uses {tuple(want)} "
                                "(layout version, n_flat, D, heads stored, head pitch, padded F): resume with the same EGOM2P_HEAD_PAD / model, "
                                "or restart the optimizer state")

@@ -47,6 +47,9 @@ int ego_gemm_small_tiles(int max_tiles128);
  * of an XCD starts `value` x ~0.5 us late (de-phases the workgroups' epilogue store bursts: tools/dephase_probe.py); 0 = off (the
  * product setting).  Returns the previous value; value < 0 only queries; unknown key: -1. */
 int ego_gemm_tune(int key, int value);
+/* The same for the attention kernels: key 1 = start delay (x 512 clocks) of the dK / dV workgroups dispatched second on their CU
+ * (phase probe of DESIGN.md section 4f; 0 = off, the product setting). */
+int ego_attn_tune(int key, int value);
 
 /* ---- front end ------------------------------------------------------------------------------- */
 

@@ -101,3 +101,17 @@ def test_head_storage_layouts():
         for HD in (66, 68, 80, 96, 100, 128):
             hdp, hs = head_layout(H, HD)
             assert hdp >= HD and hs >= H and hs - H <= 8 and (hdp * hs) % 128 == 0
+
+
+def test_top_k_count_follows_the_reference_argument_forms():
+    """`top_k_top_p_filtering` (egom2p/models/generate.py:335-342): an int top_k is a count, a float a share of the vocabulary
+    (`int(top_k * V)`), both capped at V; 0 / 0.0 switch the filter off; a share that keeps no token raises there (torch.topk(., 0)[..., -1])."""
+    import pytest
+    from egom2p_amd import ops
+    assert ops.top_k_count(0, 64000) == 0 and ops.top_k_count(0.0, 64000) == 0 and ops.top_k_count(None, 64000) == 0
+    assert ops.top_k_count(50, 64000) == 50 and ops.top_k_count(70000, 64000) == 64000
+    assert ops.top_k_count(0.001, 64000) == 64 and ops.top_k_count(0.5, 256) == 128 and ops.top_k_count(1.0, 256) == 256
+    with pytest.raises(ValueError):
+        ops.top_k_count(1e-9, 64000)
+    with pytest.raises(ValueError):
+        ops.top_k_count("3", 64000)
