@@ -65,7 +65,7 @@ def cpu_baseline(cfg, sd, synth, budgets, rank, order, n_enc, n_dec, protocol):
     # "survey-fp32" (the default): SURVEY 8(d)'s fp32 legs - one warm-up + median of 5 at B = 1 and at B = 4 - under a budget of CPU
     # seconds so that the default run stays within minutes on a slow host: a leg stops early (never below 3 timed runs) when
     # its next run would not fit, and the B = 4 leg is left out (and said so) when not even warm-up + 3 runs of it fit
-    budget = float(os.environ.get("EGOM2P_CPU_BASELINE_BUDGET_S", "300")) if protocol == "survey-fp32" else float("inf")
+    budget = float(os.environ.get("EGOM2P_CPU_BASELINE_BUDGET_S", "340")) if protocol == "survey-fp32" else float("inf")
     runs, total, notes = [], 0.0, []
     t_clip = None                                            # seconds per clip seen so far (B = 1 fp32)
     for B, mode, n_warm, n_timed in plan:
@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["survey-fp32", "quick", "full", "full-fp32", "full-bf16"], default="survey-fp32",
                     help="survey-fp32 (default): SURVEY 8(d)'s fp32 legs - warm-up + median of 5 at B = 1 and B = 4 - within a budget of "
-                         "$EGOM2P_CPU_BASELINE_BUDGET_S (300) CPU seconds; quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; "
+                         "$EGOM2P_CPU_BASELINE_BUDGET_S (340) CPU seconds; quick: warm-up + median of 3 (B=1 fp32) + one bf16-mode run; "
                          "full: fp32 and bf16 mode (~20 min)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
