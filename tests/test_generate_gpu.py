@@ -360,3 +360,10 @@ def test_whole_schedule_graph_matches_eager_generation(cfg_name, cond, target, n
         assert torch.equal(a[target]["input_mask"], b[target]["input_mask"])
         assert b[target]["target_mask"].all() and sample[target]["input_mask"].all()
     assert sum(1 for k in eng._graphs if k[0] == "generate") == 1          # one graph served all three clips
+    if n_target == 30:
+        # round 5: the top-k filter through both paths (an int count and a float share are different graphs: the key holds both)
+        for tk in (5, 0.05):
+            a = eager.generate(sample, sch, top_p=0.8, top_k=tk, seed=3)
+            b = graphed.generate_graphed(sample, sch, top_p=0.8, top_k=tk, seed=3)
+            assert torch.equal(a[target]["tensor"], b[target]["tensor"]), tk
+        assert sum(1 for k in eng._graphs if k[0] == "generate") == 3

@@ -316,6 +316,9 @@ def test_unfrozen_tensors_start_their_adamw_step_count_at_one():
     bad = dict(st, layout=(1, 2, 3, 4, 5))
     with pytest.raises(RuntimeError, match="storage layout"):
         create_optimizer(args, model).load_state_dict(bad)
+    untagged = {k: v for k, v in st.items() if k != "layout"}          # a checkpoint written before round 5: same sizes, another element order
+    with pytest.raises(RuntimeError, match="storage-layout tag"):
+        create_optimizer(args, model).load_state_dict(untagged)
 
 
 def test_training_script_resumes_where_it_stopped(tmp_path):
