@@ -7,7 +7,8 @@ against the product build (max |diff| of dQ / dK / dV), times are per launch pai
 
 Cases = the three attention sites of a training step at the bench shapes (H = 12, d = 64, N = M = 2048):
     enc    encoder self-attention: one interval [0, n_valid) per sample (uniform walk)
-    dec    decoder self-attention: block-diagonal per-row intervals 1009 / 1009 / 15 / 15
+    dec    decoder self-attention: block-diagonal per-row intervals 1009 / 1009 / 15 / 15 (the plain entry point: query tiles straddle groups)
+    decseg the same mask through the row-group entry points, as the engine launches it (tiles never straddle a group)
     cross  cross-attention: decoder queries x encoder keys, one interval per sample, separate q and kv buffers, O residual
 """
 import ctypes as C
@@ -28,7 +29,7 @@ def load(path):
     if os.path.exists(hip_rt):
         C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path)
-    for name in ("ego_attn_fwd_d64", "ego_attn_bwd_d64"):
+    for name in ("ego_attn_fwd_d64", "ego_attn_bwd_d64", "ego_attn_fwd_d64_seg", "ego_attn_bwd_d64_seg"):
         fn = getattr(lib, name)
         fn.argtypes = L._SIGS[name]
         fn.restype = C.c_int
@@ -63,8 +64,10 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     p3, pq, pkv = qkv.data_ptr(), q.data_ptr(), kv.data_ptr()
 
+    seg = torch.tensor([[0, 1009], [1009, 1009], [2018, 15], [2033, 15]], dtype=torch.int32, device=dev).repeat(B, 1, 1).contiguous()
+
     def mk(case):
-        if case in ("enc", "dec"):
+        if case in ("enc", "dec", "decseg"):
             dqkv = torch.empty_like(qkv)
             g = dqkv.data_ptr()
             r = (zero_b, nval, 1, 0) if case == "enc" else (ks, ke, N, 1)
@@ -73,6 +76,9 @@ def main():
             ba = (p3, N * 3 * D, 3 * D, p3 + 2 * D, N * 3 * D, 3 * D, p3 + 4 * D, N * 3 * D, 3 * D, o.data_ptr(), N * D, D, None,
                   do.data_ptr(), N * D, D, lse.data_ptr(), delta.data_ptr(), g, N * 3 * D, 3 * D, g + 2 * D, N * 3 * D, 3 * D,
                   g + 4 * D, N * 3 * D, 3 * D, r[0].data_ptr(), r[1].data_ptr(), r[2], r[3], B, H, N, N, 0.125, st)
+            if case == "decseg":        # (seg, n_seg, seg_bad) sit between the interval strides and B
+                fa = fa[:18] + (seg.data_ptr(), 4, None) + fa[18:]
+                ba = ba[:31] + (seg.data_ptr(), 4, None) + ba[31:]
             return fa, ba, [dqkv], (float(B) * N * N if case == "enc" else pairs_dec)
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         fa = (pq, N * D, D, pkv, N * 2 * D, 2 * D, pkv + 2 * D, N * 2 * D, 2 * D, o.data_ptr(), N * D, D, olo.data_ptr(),
@@ -83,14 +89,15 @@ def main():
         return fa, ba, [dq, dkv], float(B) * N * N
 
     out = {}
-    for case in os.environ.get("CASES", "enc,dec,cross").split(","):
+    for case in os.environ.get("CASES", "enc,dec,decseg,cross").split(","):
         fa, ba, outs, pairs = mk(case)
-        assert libs["product"].ego_attn_fwd_d64(*fa) == 0
+        fwd_name, bwd_name = ("ego_attn_fwd_d64_seg", "ego_attn_bwd_d64_seg") if case == "decseg" else ("ego_attn_fwd_d64", "ego_attn_bwd_d64")
+        assert getattr(libs["product"], fwd_name)(*fa) == 0
         ref, errs = None, {}
         for n, lib in libs.items():
             for t in outs:
                 t.zero_()
-            assert lib.ego_attn_bwd_d64(*ba) == 0, n
+            assert getattr(lib, bwd_name)(*ba) == 0, n
             torch.cuda.synchronize()
             got = [t.float().clone() for t in outs]
             if ref is None:
@@ -99,7 +106,7 @@ def main():
         times = {n: {"fwd": [], "bwd": []} for n in libs}
         for _ in range(rounds):
             for n, lib in libs.items():
-                for kind, fn, args in (("fwd", lib.ego_attn_fwd_d64, fa), ("bwd", lib.ego_attn_bwd_d64, ba)):
+                for kind, fn, args in (("fwd", getattr(lib, fwd_name), fa), ("bwd", getattr(lib, bwd_name), ba)):
                     fn(*args)
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
@@ -114,8 +121,8 @@ def main():
                      for n, t in times.items()}
         print(case, json.dumps(out[case]), flush=True)
     # one micro-batch of the step at this batch: 12 enc + 12 dec + 12 cross backward launches
-    tot = {n: round((out["enc"][n]["bwd_us_med"] + out["dec"][n]["bwd_us_med"] + out["cross"][n]["bwd_us_med"]) * 12 / 1e3, 2)
-           for n in libs} if all(c in out for c in ("enc", "dec", "cross")) else {}
+    tot = {n: round((out["enc"][n]["bwd_us_med"] + out["decseg"][n]["bwd_us_med"] + out["cross"][n]["bwd_us_med"]) * 12 / 1e3, 2)
+           for n in libs} if all(c in out for c in ("enc", "decseg", "cross")) else {}
     print("attn_bwd ms per micro-batch of", B, json.dumps(tot))
 
 
